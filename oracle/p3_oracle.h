@@ -1,0 +1,64 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY (see bb31.h).  Plain-C CPU restatement of
+ * the fib_air NTT/LDE + Poseidon2-MMCS (+ FRI/STARK glue) path.  Each function
+ * cites the reference file:line (or the absent upstream crate) it follows. */
+#ifndef P3_ORACLE_H
+#define P3_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- field helpers exported for python tests ---- */
+uint32_t p3o_to_monty(uint32_t canon);
+uint32_t p3o_from_monty(uint32_t monty);
+uint32_t p3o_add(uint32_t a, uint32_t b);
+uint32_t p3o_sub(uint32_t a, uint32_t b);
+uint32_t p3o_mul(uint32_t a, uint32_t b);
+uint32_t p3o_inv(uint32_t a);
+uint32_t p3o_pow(uint32_t a, uint64_t e);
+uint32_t p3o_two_adic_generator(unsigned bits);
+void p3o_ext_mul(const uint32_t a[4], const uint32_t b[4], uint32_t out[4]);
+void p3o_ext_inv(const uint32_t a[4], uint32_t out[4]);
+
+/* ---- dft.c ---- */
+void p3o_twiddle_table(unsigned log_n, uint32_t *out /* (1<<log_n)-1 words */);
+void p3o_bit_reverse_rows(uint32_t *dst, const uint32_t *src, size_t height, size_t width);
+void p3o_stage_in_place(uint32_t *data, size_t width, size_t height, unsigned stage,
+                        const uint32_t *stage_twiddles);
+void p3o_naive_dft(const uint32_t *in, uint32_t *out, size_t height, size_t width);
+int p3o_dft_batch(const uint32_t *in, uint32_t *out, size_t height, size_t width);
+int p3o_idft_batch(const uint32_t *in, uint32_t *out, size_t height, size_t width);
+int p3o_coset_dft_batch(const uint32_t *in, uint32_t *out, size_t height, size_t width,
+                        uint32_t shift_monty);
+int p3o_coset_lde_batch(const uint32_t *in, uint32_t *out, size_t height, size_t width,
+                        unsigned added_bits, uint32_t shift_monty, int bit_reversed_out);
+
+/* ---- poseidon2.c ---- */
+void p3o_poseidon2_permute(uint32_t state[16]);
+/* same permutation with caller-supplied (Montgomery-form) constants: KAT pinning */
+void p3o_poseidon2_permute_rc(uint32_t state[16], const uint32_t ext_init[4][16],
+                              const uint32_t internal[13], const uint32_t ext_final[4][16]);
+
+/* ---- mmcs.c ---- */
+void p3o_hash_row(const uint32_t *items, size_t n, uint32_t out[8]);
+void p3o_compress(const uint32_t left[8], const uint32_t right[8], uint32_t out[8]);
+typedef struct p3o_tree p3o_tree_t;
+/* mats[i]: row-major heights[i] x widths[i], heights powers of two. Returns NULL on bad input. */
+p3o_tree_t *p3o_mmcs_commit(const uint32_t *const *mats, const size_t *heights,
+                            const size_t *widths, size_t n_mats, uint32_t root_out[8]);
+size_t p3o_tree_num_layers(const p3o_tree_t *t);
+size_t p3o_tree_layer_len(const p3o_tree_t *t, size_t layer);
+const uint32_t *p3o_tree_layer(const p3o_tree_t *t, size_t layer); /* len*8 words */
+size_t p3o_tree_log_max_height(const p3o_tree_t *t);
+/* rows_out: concatenated opened rows (sum of widths words); path_out: log_max_height*8 words */
+int p3o_mmcs_open_batch(const p3o_tree_t *t, size_t index, uint32_t *rows_out, uint32_t *path_out);
+int p3o_mmcs_verify_batch(const uint32_t root[8], const size_t *heights, const size_t *widths,
+                          size_t n_mats, size_t index, const uint32_t *rows,
+                          const uint32_t *path, size_t path_len);
+void p3o_mmcs_free(p3o_tree_t *t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,121 @@
+/* libp3hip — C ABI of the MI355X (gfx950) backend for the fib_air NTT/LDE + Poseidon2-MMCS path.
+ *
+ * The reference (miha-stopar/Plonky3-mobile) has no C ABI: its plug points are Rust traits and five
+ * JNI exports.  Every entry point below names the reference interface it stands in
+ * for, so a Rust `backend_hip.rs` (same shape as native/src/backend_metal.rs:5-10) and a
+ * `HipMmcs: Mmcs<BabyBear>` can bind them with `extern "C"`; INTEGRATION.md shows those stubs.
+ *
+ * Conventions (carried over from the reference):
+ *   - values are u32 BabyBear Montgomery words in [0, P), P = 0x78000001 — `to_unique_u32`
+ *     (native/src/backend_vulkan.rs:2002-2005); matrices are row-major height x width;
+ *   - every function returns 0 on success or a negative P3HIP_ERR_* code and NEVER aborts; the message
+ *     goes to a per-thread take-and-clear mailbox (native/src/gpu_dft.rs:42,65-68);
+ *   - device state (tables, scratch) is per calling thread, created on first use
+ *     (native/src/backend_vulkan.rs:100-124);
+ *   - there is NO CPU fallback inside this library: on error the caller decides (the Rust GpuDft keeps
+ *     its own Radix2DitParallel fallback, native/src/gpu_dft.rs:100-112).
+ *   - `*_dev` variants take HBM pointers (hipMalloc / p3hip_malloc / a torch tensor's data_ptr) and a
+ *     hipStream_t passed as void*; they enqueue and return without synchronising.
+ */
+#ifndef P3HIP_H
+#define P3HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P3HIP_OK 0
+#define P3HIP_ERR_BAD_ARG (-1)  /* null pointer, non power-of-two height (backend_vulkan.rs:1992-1995), ... */
+#define P3HIP_ERR_HIP (-2)      /* HIP runtime failure; text via p3hip_take_last_error */
+#define P3HIP_ERR_BACKEND (-3)  /* unknown backend name (gpu_dft.rs:59) */
+#define P3HIP_ERR_INTERNAL (-4)
+
+/* BackendKind codes: gpu_dft.rs:14-40 (Cpu=0, Vulkan=1, Metal=2, WebGpu=3) plus the new Hip=4. */
+#define P3HIP_BACKEND_CPU 0
+#define P3HIP_BACKEND_VULKAN 1
+#define P3HIP_BACKEND_METAL 2
+#define P3HIP_BACKEND_WEBGPU 3
+#define P3HIP_BACKEND_HIP 4
+
+/* ---- selector + diagnostics -------------------------------------------------------------------- */
+/* set_backend_kind_from_str (gpu_dft.rs:53-63) behind JNI setBackend (lib.rs:133-146): case-insensitive
+ * "cpu" | "vulkan" | "metal" | "webgpu" | "hip"; unknown -> P3HIP_ERR_BACKEND, message "unknown backend '<x>'".
+ * Process-global relaxed atomic, default P3HIP_BACKEND_HIP. */
+int p3hip_set_backend(const char *name);
+/* get_backend_kind (gpu_dft.rs:49-51) */
+int p3hip_get_backend(void);
+/* is_vulkan_available (backend_vulkan.rs:726-731) behind JNI isVulkanAvailable (lib.rs:167-179): creates
+ * the context; writes "HIP available: <device>" or "HIP unavailable: <error>" into msg. Returns 0 if usable. */
+int p3hip_is_available(char *msg, size_t cap);
+/* take_last_vulkan_error (gpu_dft.rs:65-68): returns the calling thread's pending message and clears it;
+ * NULL when there is none.  The pointer stays valid until the next call on the same thread. */
+const char *p3hip_take_last_error(void);
+
+/* ---- device memory helpers for FFI callers that do not link HIP themselves ---------------------- */
+int p3hip_malloc(void **dev_ptr, size_t bytes);
+int p3hip_free(void *dev_ptr);
+int p3hip_upload(void *dev_dst, const void *host_src, size_t bytes);
+int p3hip_download(void *host_dst, const void *dev_src, size_t bytes);
+int p3hip_sync(void *stream);
+
+/* ---- TwoAdicSubgroupDft<BabyBear> --------------------------------------------------------------- */
+/* backend_vulkan::dft_batch (backend_vulkan.rs:1988-2063) / setup_vulkan_pipeline_plan (:1028-1031):
+ * natural row order in, natural row order out, out[k][c] = sum_i in[i][c] w^(ik).  Host pointers:
+ * upload, kernels, download, synchronise — the reference's "e2e" view (fib_air.rs:148-157). */
+int p3hip_dft_batch_bb31(const uint32_t *in, uint32_t *out, size_t height, size_t width);
+/* TwoAdicSubgroupDft::idft_batch [upstream provided method; SURVEY.md §8a R9] */
+int p3hip_idft_batch_bb31(const uint32_t *in, uint32_t *out, size_t height, size_t width);
+/* TwoAdicSubgroupDft::coset_dft_batch: coefficients -> evaluations over shift*<g>, natural order */
+int p3hip_coset_dft_batch_bb31(const uint32_t *in, uint32_t *out, size_t height, size_t width,
+                               uint32_t shift_monty);
+/* TwoAdicSubgroupDft::coset_lde_batch (+ the `.bit_reverse_rows()` TwoAdicFriPcs::commit applies when
+ * bit_reversed_out != 0).  out has (height << added_bits) rows. */
+int p3hip_coset_lde_batch_bb31(const uint32_t *in, uint32_t *out, size_t height, size_t width,
+                               unsigned added_bits, uint32_t shift_monty, int bit_reversed_out);
+/* device-resident forms — the reference's "kernel-only" view (backend_vulkan.rs:1428-1693) */
+int p3hip_dft_batch_bb31_dev(const uint32_t *d_in, uint32_t *d_out, size_t height, size_t width, void *stream);
+int p3hip_idft_batch_bb31_dev(const uint32_t *d_in, uint32_t *d_out, size_t height, size_t width, void *stream);
+int p3hip_coset_dft_batch_bb31_dev(const uint32_t *d_in, uint32_t *d_out, size_t height, size_t width,
+                                   uint32_t shift_monty, void *stream);
+int p3hip_coset_lde_batch_bb31_dev(const uint32_t *d_in, uint32_t *d_out, size_t height, size_t width,
+                                   unsigned added_bits, uint32_t shift_monty, int bit_reversed_out,
+                                   void *stream);
+/* write_bit_reversed_rows_u32 (backend_vulkan.rs:1005-1026) on device */
+int p3hip_bit_reverse_rows_dev(const uint32_t *d_in, uint32_t *d_out, size_t height, size_t width, void *stream);
+
+/* ---- Poseidon2-BabyBear-16 (default_babybear_poseidon2_16, native/src/poseidon_cpu.rs:17-18) ----- */
+/* n independent width-16 states, in place. */
+int p3hip_poseidon2_permute_dev(uint32_t *d_states, size_t n, void *stream);
+int p3hip_poseidon2_permute(uint32_t *states, size_t n);
+
+/* ---- Mmcs<BabyBear>: MerkleTreeMmcs<Poseidon2 sponge 16/8/8, TruncatedPermutation 2/8/16, digest 8>
+ *      (the Poseidon2 analogue of the Keccak MMCS wired at native/src/fib_air.rs:31-51) ------------ */
+typedef struct p3hip_tree p3hip_tree_t;
+/* Mmcs::commit: matrices are device pointers (row-major, power-of-two heights); the tree keeps every
+ * digest layer in HBM and BORROWS the matrices (they must outlive the tree).  root_out is a host buffer;
+ * the call synchronises the stream before returning the root. */
+int p3hip_mmcs_commit_dev(const uint32_t *const *d_mats, const size_t *heights, const size_t *widths,
+                          size_t n_mats, uint32_t root_out[8], p3hip_tree_t **tree_out, void *stream);
+/* as above without the root download/synchronise (root readable later via p3hip_mmcs_root) */
+int p3hip_mmcs_commit_async_dev(const uint32_t *const *d_mats, const size_t *heights, const size_t *widths,
+                                size_t n_mats, p3hip_tree_t **tree_out, void *stream);
+int p3hip_mmcs_root(const p3hip_tree_t *tree, uint32_t root_out[8], void *stream);
+size_t p3hip_mmcs_log_max_height(const p3hip_tree_t *tree);
+size_t p3hip_mmcs_num_layers(const p3hip_tree_t *tree);
+/* device pointer to digest layer `layer` (layer 0 = leaf digests), 8 words per digest */
+const uint32_t *p3hip_mmcs_layer_dev(const p3hip_tree_t *tree, size_t layer, size_t *len_out);
+/* Mmcs::open_batch: opened rows of every matrix (concatenated, host buffer of sum(widths) words) and the
+ * sibling path (host buffer of log_max_height*8 words). */
+int p3hip_mmcs_open_batch(const p3hip_tree_t *tree, size_t index, uint32_t *rows_out, uint32_t *path_out,
+                          void *stream);
+void p3hip_mmcs_free(p3hip_tree_t *tree);
+/* host-pointer convenience: uploads the matrices, commits, keeps its own device copies inside the tree */
+int p3hip_mmcs_commit(const uint32_t *const *mats, const size_t *heights, const size_t *widths,
+                      size_t n_mats, uint32_t root_out[8], p3hip_tree_t **tree_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* P3HIP_H */

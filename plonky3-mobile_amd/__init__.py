@@ -1,0 +1,13 @@
+"""plonky3-mobile_amd — MI355X (gfx950) backend for the Plonky3 fib_air hot path:
+batched BabyBear NTT / coset LDE and the Poseidon2 Merkle-tree MMCS, as hand-written HIP kernels
+behind the C ABI in include/p3hip.h.  This package is the host-side mirror of the reference's
+selector (native/src/gpu_dft.rs) and of Plonky3's Mmcs contract; it has no CPU fallback."""
+from . import _lib
+from ._lib import P3HipError, build
+from .gpu_dft import (BackendKind, GpuDft, bit_reverse_rows, dev_u32, get_backend_kind, host_u32, is_available,
+                      set_backend_kind, set_backend_kind_from_str, take_last_error, GENERATOR_MONTY, MONTY_ONE, P)
+from .mmcs import MerkleTree, MerkleTreeMmcs, poseidon2_permute
+
+__all__ = ["BackendKind", "GpuDft", "MerkleTree", "MerkleTreeMmcs", "P3HipError", "bit_reverse_rows", "build",
+           "dev_u32", "get_backend_kind", "host_u32", "is_available", "poseidon2_permute", "set_backend_kind",
+           "set_backend_kind_from_str", "take_last_error", "GENERATOR_MONTY", "MONTY_ONE", "P"]

@@ -1,0 +1,102 @@
+"""ctypes binding of libp3hip.so (include/p3hip.h).  There is no fallback: if the HIP library is
+missing or a call fails, this raises."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libp3hip.so")
+ROOT = os.path.dirname(_HERE)
+
+u32p = C.POINTER(C.c_uint32)
+_SIGS = {
+    "p3hip_set_backend": (C.c_int, [C.c_char_p]),
+    "p3hip_get_backend": (C.c_int, []),
+    "p3hip_is_available": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "p3hip_take_last_error": (C.c_char_p, []),
+    "p3hip_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "p3hip_free": (C.c_int, [C.c_void_p]),
+    "p3hip_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "p3hip_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "p3hip_sync": (C.c_int, [C.c_void_p]),
+    "p3hip_dft_batch_bb31": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
+    "p3hip_idft_batch_bb31": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
+    "p3hip_coset_dft_batch_bb31": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32]),
+    "p3hip_coset_lde_batch_bb31": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint,
+                                             C.c_uint32, C.c_int]),
+    "p3hip_dft_batch_bb31_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "p3hip_idft_batch_bb31_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "p3hip_coset_dft_batch_bb31_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32,
+                                                 C.c_void_p]),
+    "p3hip_coset_lde_batch_bb31_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint,
+                                                 C.c_uint32, C.c_int, C.c_void_p]),
+    "p3hip_bit_reverse_rows_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "p3hip_poseidon2_permute_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "p3hip_poseidon2_permute": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "p3hip_mmcs_commit_dev": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
+                                        C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
+    "p3hip_mmcs_commit_async_dev": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                              C.POINTER(C.c_size_t), C.c_size_t, C.POINTER(C.c_void_p),
+                                              C.c_void_p]),
+    "p3hip_mmcs_root": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "p3hip_mmcs_log_max_height": (C.c_size_t, [C.c_void_p]),
+    "p3hip_mmcs_num_layers": (C.c_size_t, [C.c_void_p]),
+    "p3hip_mmcs_layer_dev": (C.c_void_p, [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "p3hip_mmcs_open_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "p3hip_mmcs_free": (None, [C.c_void_p]),
+    "p3hip_mmcs_commit": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
+                                    C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]),
+}
+
+
+class P3HipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libp3hip error %d: %s" % (code, msg))
+        self.code = code
+        self.message = msg
+
+
+def build(force=False):
+    """Compile csrc/*.hip for gfx950 into libp3hip.so (hipcc cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-s", "-C", csrc, "clean"])
+    subprocess.check_call(["make", "-s", "-j4", "-C", csrc])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libp3hip.so is not built (run __graft_entry__.build()); "
+                              "there is no CPU fallback in this package")
+        # One HIP runtime per process: torch bundles its own libamdhip64.so.7 / libhsa-runtime64; load it
+        # FIRST so libp3hip's NEEDED libamdhip64.so.7 resolves to the already-loaded copy.  Loading the
+        # system runtime first and torch's second leaves torch with "No HIP GPUs are available".
+        import torch  # noqa: F401
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def declared_symbols():
+    return sorted(_SIGS)
+
+
+def take_last_error():
+    """gpu_dft.rs:65-68 take_last_vulkan_error: returns and clears the pending message."""
+    m = lib().p3hip_take_last_error()
+    return m.decode() if m else None
+
+
+def check(rc):
+    if rc != 0:
+        raise P3HipError(rc, take_last_error() or "")

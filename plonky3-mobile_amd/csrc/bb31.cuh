@@ -1,0 +1,138 @@
+// BabyBear (P = 2^31 - 2^27 + 1) Montgomery arithmetic for gfx950 device code and the C++ host side.
+// Same residue system as the reference's shaders (native/shaders/fft_stage.wgsl:36-70,
+// native/src/backend_vulkan.rs:882-917): u32 words x*2^32 mod P kept in [0, P).
+// The reduction is re-derived for CDNA4: three integer multiplies (v_mul_lo/v_mul_hi/v_mul_lo ... )
+// and branch-free min() corrections instead of the reference's compare-and-branch.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bb {
+
+constexpr uint32_t P = 0x78000001u;
+constexpr uint32_t MU = 0x88000001u;   // P^-1 mod 2^32
+constexpr uint32_t ONE = 0x0ffffffeu;  // 2^32 mod P
+constexpr uint32_t R2 = 0x45dddde3u;   // 2^64 mod P
+constexpr uint32_t GEN = 31u;          // multiplicative generator (canonical)
+constexpr uint32_t TWO_ADICITY = 27;
+
+#define BB_HD __host__ __device__ __forceinline__
+
+BB_HD uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+BB_HD uint32_t add(uint32_t a, uint32_t b) {
+    uint32_t s = a + b;  // < 2P < 2^32
+    return umin32(s, s - P);
+}
+BB_HD uint32_t sub(uint32_t a, uint32_t b) {
+    uint32_t d = a - b;
+    return umin32(d, d + P);
+}
+BB_HD uint32_t neg(uint32_t a) { return a ? P - a : 0u; }
+BB_HD uint32_t dbl(uint32_t a) { return add(a, a); }
+
+BB_HD uint32_t mulhi32(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+
+// x in [0, 2^32 * P)  ->  x * 2^-32 mod P in [0, P)
+BB_HD uint32_t monty_reduce(uint64_t x) {
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    uint32_t t = lo * MU;
+    uint32_t u = mulhi32(t, P);  // low words of x and t*P agree, so no borrow crosses bit 32
+    uint32_t r = hi - u;
+    return umin32(r, r + P);
+}
+BB_HD uint32_t mul(uint32_t a, uint32_t b) { return monty_reduce((uint64_t)a * b); }
+BB_HD uint32_t sqr(uint32_t a) { return mul(a, a); }
+BB_HD uint32_t to_monty(uint32_t canon) { return mul(canon, R2); }
+BB_HD uint32_t from_monty(uint32_t m) { return monty_reduce((uint64_t)m); }
+
+BB_HD uint32_t pow(uint32_t base, uint64_t e) {
+    uint32_t r = ONE;
+    while (e) {
+        if (e & 1) r = mul(r, base);
+        base = sqr(base);
+        e >>= 1;
+    }
+    return r;
+}
+BB_HD uint32_t inv(uint32_t a) { return pow(a, (uint64_t)P - 2); }
+
+// two_adic_generator(bits) = (31^15)^(2^(27-bits))  (backend_vulkan.rs:982)
+BB_HD uint32_t two_adic_generator(uint32_t bits) {
+    uint32_t g = pow(to_monty(GEN), 15);
+    for (uint32_t i = bits; i < TWO_ADICITY; i++) g = sqr(g);
+    return g;
+}
+
+// x^7
+BB_HD uint32_t pow7(uint32_t x) {
+    uint32_t x2 = sqr(x), x3 = mul(x2, x), x4 = sqr(x2);
+    return mul(x3, x4);
+}
+
+// ---- quartic extension F[x]/(x^4 - 11) (Challenge = BinomialExtensionField<BabyBear,4>,
+//      reference native/src/fib_air.rs:23) ----
+struct Ext {
+    uint32_t c[4];
+};
+constexpr uint32_t W_CANON = 11u;
+constexpr uint32_t W_MONTY = 0x37ffffe9u;  // 11 * 2^32 mod P
+
+BB_HD Ext ext_zero() { return Ext{{0, 0, 0, 0}}; }
+BB_HD Ext ext_from_base(uint32_t a) { return Ext{{a, 0, 0, 0}}; }
+BB_HD Ext ext_one() { return ext_from_base(ONE); }
+BB_HD Ext add(const Ext& a, const Ext& b) {
+    return Ext{{add(a.c[0], b.c[0]), add(a.c[1], b.c[1]), add(a.c[2], b.c[2]), add(a.c[3], b.c[3])}};
+}
+BB_HD Ext sub(const Ext& a, const Ext& b) {
+    return Ext{{sub(a.c[0], b.c[0]), sub(a.c[1], b.c[1]), sub(a.c[2], b.c[2]), sub(a.c[3], b.c[3])}};
+}
+BB_HD Ext neg(const Ext& a) { return Ext{{neg(a.c[0]), neg(a.c[1]), neg(a.c[2]), neg(a.c[3])}}; }
+BB_HD Ext scale(const Ext& a, uint32_t s) {
+    return Ext{{mul(a.c[0], s), mul(a.c[1], s), mul(a.c[2], s), mul(a.c[3], s)}};
+}
+BB_HD bool eq(const Ext& a, const Ext& b) {
+    return a.c[0] == b.c[0] && a.c[1] == b.c[1] && a.c[2] == b.c[2] && a.c[3] == b.c[3];
+}
+// Schoolbook product with delayed reduction: each output coefficient is a sum of at most 4 products
+// (three of them scaled by 11 afterwards), accumulated as 64-bit values below 2^32*P before ONE
+// Montgomery reduction.  a_i*b_j < P^2 < 2^62; we reduce the high part first to stay in range.
+BB_HD Ext mul(const Ext& a, const Ext& b) {
+    // t_k = sum_{i+j=k} a_i b_j  (k = 0..6), reduced individually to [0,P) via monty (keeps it simple
+    // and exact); then c_k = t_k + 11 t_{k+4}.
+    uint32_t t0 = mul(a.c[0], b.c[0]);
+    uint32_t t1 = add(mul(a.c[0], b.c[1]), mul(a.c[1], b.c[0]));
+    uint32_t t2 = add(add(mul(a.c[0], b.c[2]), mul(a.c[1], b.c[1])), mul(a.c[2], b.c[0]));
+    uint32_t t3 = add(add(mul(a.c[0], b.c[3]), mul(a.c[1], b.c[2])), add(mul(a.c[2], b.c[1]), mul(a.c[3], b.c[0])));
+    uint32_t t4 = add(add(mul(a.c[1], b.c[3]), mul(a.c[2], b.c[2])), mul(a.c[3], b.c[1]));
+    uint32_t t5 = add(mul(a.c[2], b.c[3]), mul(a.c[3], b.c[2]));
+    uint32_t t6 = mul(a.c[3], b.c[3]);
+    return Ext{{add(t0, mul(t4, W_MONTY)), add(t1, mul(t5, W_MONTY)), add(t2, mul(t6, W_MONTY)), t3}};
+}
+BB_HD Ext sqr(const Ext& a) { return mul(a, a); }
+BB_HD Ext pow(Ext base, uint64_t e) {
+    Ext r = ext_one();
+    while (e) {
+        if (e & 1) r = mul(r, base);
+        base = sqr(base);
+        e >>= 1;
+    }
+    return r;
+}
+BB_HD Ext inv(const Ext& a) {
+    Ext conj{{a.c[0], neg(a.c[1]), a.c[2], neg(a.c[3])}};
+    Ext n = mul(a, conj);  // c + d x^2
+    uint32_t c = n.c[0], d = n.c[2];
+    uint32_t den = sub(sqr(c), mul(W_MONTY, sqr(d)));
+    uint32_t di = inv(den);
+    Ext q{{mul(c, di), 0, neg(mul(d, di)), 0}};
+    return mul(conj, q);
+}
+
+}  // namespace bb

@@ -1,0 +1,301 @@
+// extern "C" surface of libp3hip (include/p3hip.h).  Thin: argument checks, context lookup, host<->device
+// staging for the host-pointer entry points.  Never throws across the boundary (JNI wrappers in the
+// reference catch panics, native/src/lib.rs:45-59; here every path returns a status code).
+#include "../../include/p3hip.h"
+
+#include <atomic>
+#include <cctype>
+#include <cstdio>
+#include <cstring>
+
+#include "bb31.cuh"
+#include "common.h"
+#include "mmcs.h"
+
+namespace p3 {
+bool take_error(std::string* out);
+}
+using namespace p3;
+
+// gpu_dft.rs:41: `static BACKEND_KIND: AtomicU8` — default is the GPU backend.
+static std::atomic<uint8_t> g_backend{P3HIP_BACKEND_HIP};
+
+template <class F>
+static int guarded(F&& f) {
+    try {
+        return f();
+    } catch (const std::exception& e) {
+        return fail(ERR_INTERNAL, std::string("exception: ") + e.what());
+    } catch (...) {
+        return fail(ERR_INTERNAL, "unknown exception");
+    }
+}
+
+extern "C" {
+
+int p3hip_set_backend(const char* name) {
+    if (!name) return fail(ERR_BACKEND, "unknown backend '<null>'");
+    std::string v;
+    for (const char* p = name; *p; ++p) v.push_back((char)std::tolower((unsigned char)*p));
+    uint8_t kind;
+    if (v == "cpu") kind = P3HIP_BACKEND_CPU;
+    else if (v == "vulkan") kind = P3HIP_BACKEND_VULKAN;
+    else if (v == "metal") kind = P3HIP_BACKEND_METAL;
+    else if (v == "webgpu") kind = P3HIP_BACKEND_WEBGPU;
+    else if (v == "hip") kind = P3HIP_BACKEND_HIP;
+    else return fail(ERR_BACKEND, "unknown backend '" + v + "'");
+    g_backend.store(kind, std::memory_order_relaxed);
+    return OK;
+}
+
+int p3hip_get_backend(void) { return g_backend.load(std::memory_order_relaxed); }
+
+int p3hip_is_available(char* msg, size_t cap) {
+    return guarded([&]() -> int {
+        Context* cx = nullptr;
+        int rc = get_context(&cx);
+        std::string text;
+        if (rc == OK) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, cx->device) == hipSuccess)
+                text = std::string("HIP available: ") + prop.name + " (" + prop.gcnArchName + ")";
+            else
+                text = "HIP available";
+        } else {
+            std::string err;
+            take_error(&err);
+            text = "HIP unavailable: " + err;
+            set_error(err);
+        }
+        if (msg && cap) snprintf(msg, cap, "%s", text.c_str());
+        return rc;
+    });
+}
+
+const char* p3hip_take_last_error(void) {
+    static thread_local std::string held;
+    if (!take_error(&held)) return nullptr;
+    return held.c_str();
+}
+
+int p3hip_malloc(void** dev_ptr, size_t bytes) {
+    if (!dev_ptr) return fail(ERR_BAD_ARG, "p3hip_malloc: null out pointer");
+    Context* cx;
+    int rc = get_context(&cx);
+    if (rc) return rc;
+    P3_HIP(hipMalloc(dev_ptr, bytes ? bytes : 4));
+    return OK;
+}
+int p3hip_free(void* dev_ptr) {
+    if (dev_ptr) P3_HIP(hipFree(dev_ptr));
+    return OK;
+}
+int p3hip_upload(void* dev_dst, const void* host_src, size_t bytes) {
+    if (bytes && (!dev_dst || !host_src)) return fail(ERR_BAD_ARG, "p3hip_upload: null pointer");
+    if (bytes) P3_HIP(hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice));
+    return OK;
+}
+int p3hip_download(void* host_dst, const void* dev_src, size_t bytes) {
+    if (bytes && (!host_dst || !dev_src)) return fail(ERR_BAD_ARG, "p3hip_download: null pointer");
+    if (bytes) P3_HIP(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
+    return OK;
+}
+int p3hip_sync(void* stream) {
+    P3_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return OK;
+}
+
+}  // extern "C"
+
+// ---- TwoAdicSubgroupDft ------------------------------------------------------------------------
+enum DftOp { OP_DFT, OP_IDFT, OP_COSET_DFT, OP_COSET_LDE };
+
+static int dft_dev(DftOp op, const uint32_t* d_in, uint32_t* d_out, size_t h, size_t w, unsigned added_bits,
+                   uint32_t shift, int br_out, hipStream_t stream) {
+    return guarded([&]() -> int {
+        if (h == 0 || w == 0) return OK;
+        if (!d_in || !d_out) return fail(ERR_BAD_ARG, "null matrix pointer");
+        if (w > 0xffffffffull) return fail(ERR_BAD_ARG, "width too large");
+        if (shift >= bb::P) return fail(ERR_BAD_ARG, "shift is not a reduced Montgomery word");
+        Context* cx;
+        int rc = get_context(&cx);
+        if (rc) return rc;
+        switch (op) {
+            case OP_DFT: return ntt_dft(*cx, stream, d_in, d_out, h, (uint32_t)w, false);
+            case OP_IDFT: return ntt_dft(*cx, stream, d_in, d_out, h, (uint32_t)w, true);
+            case OP_COSET_DFT: return ntt_coset_dft(*cx, stream, d_in, d_out, h, (uint32_t)w, shift);
+            default: return ntt_coset_lde(*cx, stream, d_in, d_out, h, (uint32_t)w, added_bits, shift, br_out != 0);
+        }
+    });
+}
+
+// host-pointer path: H2D, kernels, D2H, sync (the reference's e2e shape, backend_vulkan.rs:1107-1394)
+static int dft_host(DftOp op, const uint32_t* in, uint32_t* out, size_t h, size_t w, unsigned added_bits,
+                    uint32_t shift, int br_out) {
+    return guarded([&]() -> int {
+        if (h == 0 || w == 0) return OK;
+        if (!in || !out) return fail(ERR_BAD_ARG, "null matrix pointer");
+        if (!is_pow2(h)) return fail(ERR_BAD_ARG, "hip backend requires power-of-two height, got " + std::to_string(h));
+        Context* cx;
+        int rc = get_context(&cx);
+        if (rc) return rc;
+        size_t in_bytes = h * w * 4;
+        size_t out_rows = op == OP_COSET_LDE ? (h << added_bits) : h;
+        size_t out_bytes = out_rows * w * 4;
+        rc = cx->ws[2].reserve(in_bytes);
+        if (rc) return rc;
+        rc = cx->ws[3].reserve(out_bytes);
+        if (rc) return rc;
+        hipStream_t stream = nullptr;
+        P3_HIP(hipMemcpyAsync(cx->ws[2].ptr, in, in_bytes, hipMemcpyHostToDevice, stream));
+        rc = dft_dev(op, cx->ws[2].as<uint32_t>(), cx->ws[3].as<uint32_t>(), h, w, added_bits, shift, br_out, stream);
+        if (rc) return rc;
+        P3_HIP(hipMemcpyAsync(out, cx->ws[3].ptr, out_bytes, hipMemcpyDeviceToHost, stream));
+        P3_HIP(hipStreamSynchronize(stream));
+        return OK;
+    });
+}
+
+extern "C" {
+
+int p3hip_dft_batch_bb31(const uint32_t* in, uint32_t* out, size_t h, size_t w) {
+    return dft_host(OP_DFT, in, out, h, w, 0, bb::ONE, 0);
+}
+int p3hip_idft_batch_bb31(const uint32_t* in, uint32_t* out, size_t h, size_t w) {
+    return dft_host(OP_IDFT, in, out, h, w, 0, bb::ONE, 0);
+}
+int p3hip_coset_dft_batch_bb31(const uint32_t* in, uint32_t* out, size_t h, size_t w, uint32_t shift) {
+    return dft_host(OP_COSET_DFT, in, out, h, w, 0, shift, 0);
+}
+int p3hip_coset_lde_batch_bb31(const uint32_t* in, uint32_t* out, size_t h, size_t w, unsigned added_bits,
+                               uint32_t shift, int br_out) {
+    return dft_host(OP_COSET_LDE, in, out, h, w, added_bits, shift, br_out);
+}
+int p3hip_dft_batch_bb31_dev(const uint32_t* in, uint32_t* out, size_t h, size_t w, void* stream) {
+    return dft_dev(OP_DFT, in, out, h, w, 0, bb::ONE, 0, (hipStream_t)stream);
+}
+int p3hip_idft_batch_bb31_dev(const uint32_t* in, uint32_t* out, size_t h, size_t w, void* stream) {
+    return dft_dev(OP_IDFT, in, out, h, w, 0, bb::ONE, 0, (hipStream_t)stream);
+}
+int p3hip_coset_dft_batch_bb31_dev(const uint32_t* in, uint32_t* out, size_t h, size_t w, uint32_t shift, void* stream) {
+    return dft_dev(OP_COSET_DFT, in, out, h, w, 0, shift, 0, (hipStream_t)stream);
+}
+int p3hip_coset_lde_batch_bb31_dev(const uint32_t* in, uint32_t* out, size_t h, size_t w, unsigned added_bits,
+                                   uint32_t shift, int br_out, void* stream) {
+    return dft_dev(OP_COSET_LDE, in, out, h, w, added_bits, shift, br_out, (hipStream_t)stream);
+}
+int p3hip_bit_reverse_rows_dev(const uint32_t* in, uint32_t* out, size_t h, size_t w, void* stream) {
+    return guarded([&]() -> int {
+        if (h == 0 || w == 0) return OK;
+        if (!in || !out || in == out) return fail(ERR_BAD_ARG, "bit_reverse_rows: null or aliased pointers");
+        return bit_reverse_rows((hipStream_t)stream, in, out, h, (uint32_t)w);
+    });
+}
+
+// ---- Poseidon2 ----------------------------------------------------------------------------------
+int p3hip_poseidon2_permute_dev(uint32_t* d_states, size_t n, void* stream) {
+    return guarded([&]() -> int {
+        if (n && !d_states) return fail(ERR_BAD_ARG, "null state pointer");
+        Context* cx;
+        int rc = get_context(&cx);
+        if (rc) return rc;
+        return poseidon2_permute_states((hipStream_t)stream, d_states, n);
+    });
+}
+int p3hip_poseidon2_permute(uint32_t* states, size_t n) {
+    return guarded([&]() -> int {
+        if (!n) return OK;
+        if (!states) return fail(ERR_BAD_ARG, "null state pointer");
+        Context* cx;
+        int rc = get_context(&cx);
+        if (rc) return rc;
+        rc = cx->ws[2].reserve(n * 64);
+        if (rc) return rc;
+        P3_HIP(hipMemcpy(cx->ws[2].ptr, states, n * 64, hipMemcpyHostToDevice));
+        rc = poseidon2_permute_states(nullptr, cx->ws[2].as<uint32_t>(), n);
+        if (rc) return rc;
+        P3_HIP(hipMemcpy(states, cx->ws[2].ptr, n * 64, hipMemcpyDeviceToHost));
+        return OK;
+    });
+}
+
+// ---- Mmcs ---------------------------------------------------------------------------------------
+struct p3hip_tree {
+    Tree* t;
+};
+
+int p3hip_mmcs_commit_async_dev(const uint32_t* const* d_mats, const size_t* heights, const size_t* widths,
+                                size_t n_mats, p3hip_tree_t** tree_out, void* stream) {
+    return guarded([&]() -> int {
+        if (!tree_out) return fail(ERR_BAD_ARG, "mmcs_commit: null tree_out");
+        Context* cx;
+        int rc = get_context(&cx);
+        if (rc) return rc;
+        Tree* t = nullptr;
+        rc = mmcs_commit((hipStream_t)stream, d_mats, heights, widths, n_mats, &t);
+        if (rc) return rc;
+        *tree_out = new p3hip_tree{t};
+        return OK;
+    });
+}
+int p3hip_mmcs_root(const p3hip_tree_t* tree, uint32_t root_out[8], void* stream) {
+    return guarded([&]() -> int {
+        if (!tree || !root_out) return fail(ERR_BAD_ARG, "mmcs_root: null argument");
+        return mmcs_root((hipStream_t)stream, *tree->t, root_out);
+    });
+}
+int p3hip_mmcs_commit_dev(const uint32_t* const* d_mats, const size_t* heights, const size_t* widths,
+                          size_t n_mats, uint32_t root_out[8], p3hip_tree_t** tree_out, void* stream) {
+    if (!root_out) return fail(ERR_BAD_ARG, "mmcs_commit: null root_out");
+    int rc = p3hip_mmcs_commit_async_dev(d_mats, heights, widths, n_mats, tree_out, stream);
+    if (rc) return rc;
+    rc = p3hip_mmcs_root(*tree_out, root_out, stream);
+    if (rc) { p3hip_mmcs_free(*tree_out); *tree_out = nullptr; }
+    return rc;
+}
+size_t p3hip_mmcs_log_max_height(const p3hip_tree_t* tree) { return tree ? tree->t->log_max_height : 0; }
+size_t p3hip_mmcs_num_layers(const p3hip_tree_t* tree) { return tree ? tree->t->layer_len.size() : 0; }
+const uint32_t* p3hip_mmcs_layer_dev(const p3hip_tree_t* tree, size_t layer, size_t* len_out) {
+    if (!tree || layer >= tree->t->layer_len.size()) return nullptr;
+    if (len_out) *len_out = tree->t->layer_len[layer];
+    return tree->t->layers + tree->t->layer_off[layer];
+}
+int p3hip_mmcs_open_batch(const p3hip_tree_t* tree, size_t index, uint32_t* rows_out, uint32_t* path_out,
+                          void* stream) {
+    return guarded([&]() -> int {
+        if (!tree) return fail(ERR_BAD_ARG, "mmcs_open_batch: null tree");
+        return mmcs_open((hipStream_t)stream, *tree->t, index, rows_out, path_out);
+    });
+}
+void p3hip_mmcs_free(p3hip_tree_t* tree) {
+    if (!tree) return;
+    delete tree->t;
+    delete tree;
+}
+int p3hip_mmcs_commit(const uint32_t* const* mats, const size_t* heights, const size_t* widths, size_t n_mats,
+                      uint32_t root_out[8], p3hip_tree_t** tree_out) {
+    return guarded([&]() -> int {
+        if (!mats || !heights || !widths || !n_mats || !root_out || !tree_out)
+            return fail(ERR_BAD_ARG, "mmcs_commit: null/empty argument");
+        Context* cx;
+        int rc = get_context(&cx);
+        if (rc) return rc;
+        std::vector<void*> owned;
+        std::vector<const uint32_t*> dptr;
+        auto cleanup = [&]() { for (void* p : owned) (void)hipFree(p); };
+        for (size_t i = 0; i < n_mats; i++) {
+            size_t bytes = heights[i] * widths[i] * 4;
+            void* d = nullptr;
+            if (hipMalloc(&d, bytes ? bytes : 4) != hipSuccess) { cleanup(); return fail(ERR_HIP, "hipMalloc failed"); }
+            owned.push_back(d);
+            if (bytes && hipMemcpy(d, mats[i], bytes, hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return fail(ERR_HIP, "hipMemcpy failed"); }
+            dptr.push_back((const uint32_t*)d);
+        }
+        rc = p3hip_mmcs_commit_dev(dptr.data(), heights, widths, n_mats, root_out, tree_out, nullptr);
+        if (rc) { cleanup(); return rc; }
+        (*tree_out)->t->owned = owned;
+        return OK;
+    });
+}
+
+}  // extern "C"

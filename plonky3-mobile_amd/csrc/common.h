@@ -1,0 +1,87 @@
+// Shared host-side plumbing for libp3hip: error mailbox, per-thread device context, cached tables.
+// Conventions carried over from the reference: errors are values (status code +
+// take-and-clear message, native/src/gpu_dft.rs:42,65-68), device state is per calling thread
+// (native/src/backend_vulkan.rs:100-124), nothing aborts.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+namespace p3 {
+
+enum Status : int {
+    OK = 0,
+    ERR_BAD_ARG = -1,   // null pointer / non power-of-two height / bad width
+    ERR_HIP = -2,       // HIP runtime failure (message in take_last_error)
+    ERR_BACKEND = -3,   // unknown backend name, or hip backend not selected
+    ERR_INTERNAL = -4,
+};
+
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define P3_HIP(call)                                                                       \
+    do {                                                                                   \
+        hipError_t e__ = (call);                                                           \
+        if (e__ != hipSuccess)                                                             \
+            return p3::fail(p3::ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+// Growable device scratch buffer (never shrinks; freed with the context).
+struct DevBuf {
+    void* ptr = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(ptr); }
+    ~DevBuf();
+};
+
+struct TwoLevelTable {  // value(e) = lo[e & (2^T - 1)] * hi[e >> T]
+    uint32_t* lo = nullptr;
+    uint32_t* hi = nullptr;
+    uint32_t T = 0;
+};
+
+struct Context {
+    int device = -1;
+    uint32_t* tile_tw[2] = {nullptr, nullptr};  // [inverse]: reference-layout stage tables, 2^11-1 words
+    std::map<std::pair<uint32_t, int>, TwoLevelTable> root_tables;            // (q, inverse) -> w_{2^q}^e
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t>, TwoLevelTable> scale_tables;  // (base, log_n, mult)
+    DevBuf ws[4];  // scratch slabs (ntt ping-pong, lde coefficients, ...)
+    int init();
+    int get_root_table(uint32_t q, bool inverse, TwoLevelTable* out);
+    // value(j) = mult * base^j for j < 2^log_n
+    int get_scale_table(uint32_t base, uint32_t log_n, uint32_t mult, TwoLevelTable* out);
+    ~Context();
+};
+
+// Per-thread context, created on first use.
+int get_context(Context** out);
+
+// ---- ntt.hip ----
+// All pointers are device pointers; launches are enqueued on `stream` and not synchronised.
+// dft: natural order in, natural order out (TwoAdicSubgroupDft::dft_batch).  inverse=true gives idft_batch.
+int ntt_dft(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* dst, uint64_t height,
+            uint32_t width, bool inverse);
+// coset_lde: src = evaluations over the order-`height` subgroup (natural order), dst =
+// (height << added_bits) x width evaluations over shift*<g>, natural or bit-reversed row order.
+int ntt_coset_lde(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* dst, uint64_t height,
+                  uint32_t width, uint32_t added_bits, uint32_t shift_monty, bool bit_reversed_out);
+// coset_dft: coefficients (natural order) -> evaluations over shift*<g> (natural order).
+int ntt_coset_dft(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* dst, uint64_t height,
+                  uint32_t width, uint32_t shift_monty);
+int bit_reverse_rows(hipStream_t stream, const uint32_t* src, uint32_t* dst, uint64_t height, uint32_t width);
+
+inline bool is_pow2(uint64_t v) { return v && !(v & (v - 1)); }
+inline uint32_t log2u(uint64_t v) {
+    uint32_t l = 0;
+    while ((1ull << l) < v) l++;
+    return l;
+}
+
+}  // namespace p3

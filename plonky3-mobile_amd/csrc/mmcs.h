@@ -1,0 +1,27 @@
+// Merkle-tree prover data kept in HBM (Plonky3 MerkleTree<..>: leaves + digest_layers).
+#pragma once
+#include <memory>
+#include <cstring>
+#include "common.h"
+
+namespace p3 {
+
+struct Tree {
+    std::vector<const uint32_t*> mats;  // borrowed device pointers (or entries of `owned`)
+    std::vector<size_t> heights, widths;
+    std::vector<void*> owned;           // device copies made by the host-pointer commit
+    uint32_t* layers = nullptr;         // all digest layers, leaf layer first, 8 words per digest
+    std::vector<size_t> layer_off, layer_len;  // offsets in words / lengths in digests
+    uint32_t log_max_height = 0;
+    uint32_t* staging = nullptr;        // open_batch gather buffer
+    size_t staging_words = 0;
+    ~Tree();
+};
+
+int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t* heights, const size_t* widths,
+                size_t n_mats, Tree** out);
+int mmcs_root(hipStream_t stream, const Tree& t, uint32_t root_out[8]);
+int mmcs_open(hipStream_t stream, const Tree& t, uint64_t index, uint32_t* rows_out, uint32_t* path_out);
+int poseidon2_permute_states(hipStream_t stream, uint32_t* d_states, uint64_t n);
+
+}  // namespace p3

@@ -1,0 +1,275 @@
+// Poseidon2 Merkle-tree MMCS on gfx950: leaf sponge, 2-to-1 compression layers, openings.
+// Stands in for Plonky3's MerkleTreeMmcs (the reference passes the Keccak flavour into the PCS at
+// native/src/fib_air.rs:40-51; north_star asks for the Poseidon2 one):
+//   leaf     PaddingFreeSponge<Perm16, 16, 8, 8>   overwrite-mode absorb, permute per full/partial chunk
+//   compress TruncatedPermutation<Perm16, 2, 8, 16> state = left||right, permute, first 8 words
+//   tree     digest layer l+1[i] = compress(layer l[2i], layer l[2i+1]); matrices whose height equals a
+//            layer's length are hashed row-wise and compressed in (compress_and_inject); all layers stay
+//            in HBM for open_batch.
+// One permutation per lane, state in VGPRs; digests are 32-byte records read/written as 2 x dwordx4.
+#include "common.h"
+#include "mmcs.h"
+#include "poseidon2.cuh"
+
+namespace p3 {
+
+constexpr int MAX_CLASS_MATS = 16;
+
+struct RowSet {  // the matrices of one height class, concatenated row-wise
+    const uint32_t* ptr[MAX_CLASS_MATS];
+    uint32_t width[MAX_CLASS_MATS];
+    uint32_t count;
+    uint32_t total;
+};
+
+__device__ __forceinline__ void load_digest(const uint32_t* p, uint32_t* out8) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1];
+    out8[0] = a.x; out8[1] = a.y; out8[2] = a.z; out8[3] = a.w;
+    out8[4] = b.x; out8[5] = b.y; out8[6] = b.z; out8[7] = b.w;
+}
+__device__ __forceinline__ void store_digest(uint32_t* p, const uint32_t* s) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(s[0], s[1], s[2], s[3]);
+    q[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+
+// PaddingFreeSponge over the concatenated row `r` of the set; leaves the digest in s[0..8).
+__device__ __forceinline__ void sponge_row(const RowSet& rs, uint64_t r, uint32_t (&s)[16]) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = 0;
+    if (rs.count == 1) {
+        const uint32_t* row = rs.ptr[0] + r * rs.width[0];
+        const uint32_t w = rs.width[0];
+        for (uint32_t k = 0; k < w; k += 8) {
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (k + i < w) s[i] = row[k + i];
+            p2::permute(s);
+        }
+        return;
+    }
+    uint32_t m = 0, off = 0;  // current matrix and column inside it
+    for (uint32_t k = 0; k < rs.total; k += 8) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (k + i < rs.total) {
+                while (off >= rs.width[m]) { m++; off = 0; }
+                s[i] = rs.ptr[m][r * rs.width[m] + off];
+                off++;
+            }
+        }
+        p2::permute(s);
+    }
+}
+
+__global__ void __launch_bounds__(256) leaf_hash_kernel(RowSet rs, uint64_t n_rows, uint32_t* digests) {
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    uint32_t s[16];
+    sponge_row(rs, r, s);
+    store_digest(digests + r * 8, s);
+}
+
+// next[i] = compress(prev[2i], prev[2i+1]), optionally followed by compress(., sponge(row i of the set)).
+__global__ void __launch_bounds__(256) compress_layer_kernel(const uint32_t* prev, uint32_t* next, uint64_t n_out,
+                                                             RowSet rs, uint32_t inject) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    uint32_t s[16];
+    load_digest(prev + i * 16, s);
+    load_digest(prev + i * 16 + 8, s + 8);
+    p2::permute(s);
+    if (inject) {
+        uint32_t h[16];
+        sponge_row(rs, i, h);
+#pragma unroll
+        for (int k = 0; k < 8; k++) s[8 + k] = h[k];
+        p2::permute(s);
+    }
+    store_digest(next + i * 8, s);
+}
+
+// Finishes a tree whose current layer has at most 2*blockDim digests: all remaining (injection-free)
+// levels inside one workgroup, current layer mirrored in LDS.  layers: consecutive layers in HBM,
+// layer with n digests followed by the one with n/2.
+__global__ void __launch_bounds__(256) tree_top_kernel(uint32_t* layer0, uint32_t n0) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < n0 * 8; i += blockDim.x) lds[i] = layer0[i];
+    __syncthreads();
+    uint32_t* out = layer0 + (size_t)n0 * 8;
+    for (uint32_t n = n0; n > 1; n >>= 1) {
+        uint32_t half = n >> 1;
+        uint32_t s[16];
+        bool act = tid < half;
+        if (act) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) s[k] = lds[tid * 16 + k];
+            p2::permute(s);
+        }
+        __syncthreads();
+        if (act) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) lds[tid * 8 + k] = s[k];
+            store_digest(out + tid * 8, s);
+        }
+        __syncthreads();
+        out += (size_t)half * 8;
+    }
+}
+
+__global__ void poseidon2_permute_kernel(uint32_t* states, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s[16];
+    uint4* q = reinterpret_cast<uint4*>(states + i * 16);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { uint4 v = q[k]; s[4 * k] = v.x; s[4 * k + 1] = v.y; s[4 * k + 2] = v.z; s[4 * k + 3] = v.w; }
+    p2::permute(s);
+#pragma unroll
+    for (int k = 0; k < 4; k++) q[k] = make_uint4(s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]);
+}
+
+int poseidon2_permute_states(hipStream_t stream, uint32_t* d_states, uint64_t n) {
+    if (!n) return OK;
+    hipLaunchKernelGGL(poseidon2_permute_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_states, n);
+    P3_HIP(hipGetLastError());
+    return OK;
+}
+
+// Gathers one opening (rows of every matrix + sibling path) into a packed staging buffer.
+struct OpenArgs {
+    const uint32_t* mat[64];
+    uint32_t width[64];
+    uint32_t shift[64];  // log_max_height - log_height
+    uint32_t n_mats;
+    uint32_t log_max_height;
+};
+__global__ void open_gather_kernel(OpenArgs a, const uint32_t* layers, uint64_t index, uint32_t* out) {
+    // rows
+    uint32_t off = 0;
+    for (uint32_t m = 0; m < a.n_mats; m++) {
+        uint64_t r = index >> a.shift[m];
+        for (uint32_t c = threadIdx.x; c < a.width[m]; c += blockDim.x) out[off + c] = a.mat[m][r * a.width[m] + c];
+        off += a.width[m];
+    }
+    // siblings: layer i starts at sum_{j<i} (maxh >> j) * 8 words
+    uint64_t base = 0, len = 1ull << a.log_max_height;
+    for (uint32_t i = 0; i < a.log_max_height; i++) {
+        uint64_t sib = (index >> i) ^ 1;
+        if (threadIdx.x < 8) out[off + i * 8 + threadIdx.x] = layers[base + sib * 8 + threadIdx.x];
+        base += len * 8;
+        len >>= 1;
+    }
+}
+
+static RowSet make_rowset(const Tree& t, uint64_t h) {
+    RowSet rs{};
+    for (size_t m = 0; m < t.mats.size(); m++)
+        if (t.heights[m] == h) {
+            rs.ptr[rs.count] = t.mats[m];
+            rs.width[rs.count] = (uint32_t)t.widths[m];
+            rs.total += (uint32_t)t.widths[m];
+            rs.count++;
+        }
+    return rs;
+}
+
+Tree::~Tree() {
+    if (layers) (void)hipFree(layers);
+    if (staging) (void)hipFree(staging);
+    for (void* p : owned) (void)hipFree(p);
+}
+
+int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t* heights, const size_t* widths,
+                size_t n_mats, Tree** out) {
+    if (!n_mats || !d_mats || !heights || !widths || !out) return fail(ERR_BAD_ARG, "mmcs_commit: null/empty argument");
+    if (n_mats > 64) return fail(ERR_BAD_ARG, "mmcs_commit: at most 64 matrices per commitment");
+    uint64_t maxh = 0;
+    for (size_t i = 0; i < n_mats; i++) {
+        if (!is_pow2(heights[i])) return fail(ERR_BAD_ARG, "mmcs_commit: heights must be powers of two");
+        if (widths[i] > 0xffffffffull) return fail(ERR_BAD_ARG, "mmcs_commit: width too large");
+        if (heights[i] > maxh) maxh = heights[i];
+    }
+    std::unique_ptr<Tree> t(new Tree());
+    for (size_t i = 0; i < n_mats; i++) { t->mats.push_back(d_mats[i]); t->heights.push_back(heights[i]); t->widths.push_back(widths[i]); }
+    t->log_max_height = log2u(maxh);
+    for (uint64_t h = maxh; h >= 1; h >>= 1) {
+        size_t cnt = 0;
+        for (size_t i = 0; i < n_mats; i++) cnt += heights[i] == h;
+        if (cnt > MAX_CLASS_MATS) return fail(ERR_BAD_ARG, "mmcs_commit: more than 16 matrices of one height");
+        if (h == 1) break;
+    }
+    size_t total_digests = 2 * maxh - 1;
+    size_t staging_words = 0;
+    for (size_t i = 0; i < n_mats; i++) staging_words += widths[i];
+    staging_words += (size_t)t->log_max_height * 8 + 8;
+    t->staging_words = staging_words;
+    P3_HIP(hipMalloc(reinterpret_cast<void**>(&t->layers), total_digests * 32));
+    P3_HIP(hipMalloc(reinterpret_cast<void**>(&t->staging), staging_words * 4));
+    size_t off = 0;
+    for (uint64_t len = maxh; len >= 1; len >>= 1) {
+        t->layer_off.push_back(off);
+        t->layer_len.push_back(len);
+        off += len * 8;
+        if (len == 1) break;
+    }
+    // leaf layer
+    {
+        RowSet rs = make_rowset(*t, maxh);
+        hipLaunchKernelGGL(leaf_hash_kernel, dim3((uint32_t)((maxh + 255) / 256)), dim3(256), 0, stream, rs, maxh, t->layers);
+        P3_HIP(hipGetLastError());
+    }
+    for (size_t l = 1; l < t->layer_len.size(); l++) {
+        uint64_t len = t->layer_len[l];
+        RowSet rs = make_rowset(*t, len);
+        bool inject = rs.count > 0;
+        // remaining levels injection-free and small: finish inside one workgroup
+        bool more_inject = false;
+        for (size_t i = 0; i < n_mats; i++) more_inject |= heights[i] <= len;
+        if (!more_inject && t->layer_len[l - 1] <= 512) {
+            uint32_t n0 = (uint32_t)t->layer_len[l - 1];
+            hipLaunchKernelGGL(tree_top_kernel, dim3(1), dim3(256), (size_t)n0 * 32, stream, t->layers + t->layer_off[l - 1], n0);
+            P3_HIP(hipGetLastError());
+            break;
+        }
+        hipLaunchKernelGGL(compress_layer_kernel, dim3((uint32_t)((len + 255) / 256)), dim3(256), 0, stream,
+                           t->layers + t->layer_off[l - 1], t->layers + t->layer_off[l], len, rs, inject ? 1u : 0u);
+        P3_HIP(hipGetLastError());
+    }
+    *out = t.release();
+    return OK;
+}
+
+int mmcs_root(hipStream_t stream, const Tree& t, uint32_t root_out[8]) {
+    P3_HIP(hipMemcpyAsync(root_out, t.layers + t.layer_off.back(), 32, hipMemcpyDeviceToHost, stream));
+    P3_HIP(hipStreamSynchronize(stream));
+    return OK;
+}
+
+int mmcs_open(hipStream_t stream, const Tree& t, uint64_t index, uint32_t* rows_out, uint32_t* path_out) {
+    if (index >> t.log_max_height) return fail(ERR_BAD_ARG, "mmcs_open: index out of range");
+    OpenArgs a{};
+    a.n_mats = (uint32_t)t.mats.size();
+    a.log_max_height = t.log_max_height;
+    size_t row_words = 0;
+    for (size_t m = 0; m < t.mats.size(); m++) {
+        a.mat[m] = t.mats[m];
+        a.width[m] = (uint32_t)t.widths[m];
+        a.shift[m] = t.log_max_height - log2u(t.heights[m]);
+        row_words += t.widths[m];
+    }
+    hipLaunchKernelGGL(open_gather_kernel, dim3(1), dim3(64), 0, stream, a, t.layers, index, t.staging);
+    P3_HIP(hipGetLastError());
+    std::vector<uint32_t> host(row_words + (size_t)t.log_max_height * 8);
+    if (!host.empty()) {
+        P3_HIP(hipMemcpyAsync(host.data(), t.staging, host.size() * 4, hipMemcpyDeviceToHost, stream));
+        P3_HIP(hipStreamSynchronize(stream));
+    }
+    if (row_words) memcpy(rows_out, host.data(), row_words * 4);
+    if (t.log_max_height) memcpy(path_out, host.data() + row_words, (size_t)t.log_max_height * 32);
+    return OK;
+}
+
+}  // namespace p3

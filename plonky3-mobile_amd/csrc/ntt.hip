@@ -1,0 +1,484 @@
+// Batched radix-2 NTT / coset LDE over BabyBear for gfx950.
+//
+// Replaces the reference's per-stage Vulkan dispatch loop (native/src/backend_vulkan.rs:1182-1294,
+// kernels native/shaders/fft_stage.wgsl:75-136 and fft_stage_fused.wgsl:67-139), which costs log2(H)
+// full HBM round trips.  Here a transform of 2^n rows is cut into 1-3 PASSES of b <= 11 stages; a
+// workgroup stages a [2^b points] x [RUN independent words] tile in LDS (row stride RUN+1, so both
+// the row-wise and the column-wise copies are bank-conflict free), runs the b stages as register
+// radix-2^r rounds (r <= 5, one LDS round trip per round), and writes the tile back once.  Passes
+// talk to HBM only in runs of RUN*4 = 64..128 contiguous bytes.
+//
+//   DIT plan (natural in -> natural out): the first pass gathers rows in bit-reversed order (runs of
+//     RUN/W consecutive rows), later passes are in place with a pre-twiddle w_{2^(s0+b)}^(rev(pt)*lo).
+//   DIF plan (natural in -> bit-reversed or natural out): top digit first, post-twiddle after the tile
+//     transform; zero padding and the coset/1/N scaling are folded into the first pass's loads.
+//
+// Row-major H x W matrices of Montgomery words, exactly the buffers the reference uploads
+// (backend_vulkan.rs:2002-2005).  Stage semantics inside a tile are those of cpu_stage_u32_in_place
+// (backend_vulkan.rs:881-942) with the same twiddle-table layout (:977-996: stage k at offset 2^k-1).
+#include "bb31.cuh"
+#include "common.h"
+
+namespace p3 {
+
+enum SideKind : uint32_t {
+    SIDE_INPLACE = 0,   // word = ((hi << (s0+b)) + (pt << s0)) * W + f          (s0 > 0)
+    SIDE_GROUP = 1,     // word = (((h0+t) << b) + pt) * W + c                   (contiguous groups)
+    SIDE_GROUP_REV = 2, // word = ((rev(h0+t) << b) + pt) * W + c
+    SIDE_STRIDED = 3,   // word = ((rev_b(pt) << (n-b)) + h0 + t) * W + c        (bit-reversal gather/scatter)
+};
+
+struct PassArgs {
+    const uint32_t* src;
+    uint32_t* dst;
+    uint64_t src_rows;  // natural rows >= src_rows load as zero (zero padding)
+    uint32_t W, wshift; // wshift = log2(W) if W is a power of two, else 0xffffffff
+    uint32_t n, b, s0;
+    uint32_t dif;       // 0: DIT tile (bit-reversed in, natural out); 1: DIF tile (natural in, bit-reversed out)
+    uint32_t load_kind, store_kind;
+    uint32_t G;         // groups per tile when W < RUN (group modes)
+    uint32_t n_inner;   // inner tile count (column chunks / flattened runs)
+    const uint32_t* tile_tw;
+    uint32_t has_tw;    // pre (DIT) / post (DIF) twiddle w_{2^(s0+b)}^(rev_b(pt) * lo)
+    const uint32_t* tw_lo;
+    const uint32_t* tw_hi;
+    uint32_t tw_T;
+    uint32_t has_sc;    // multiply loaded value by sc(row)
+    const uint32_t* sc_lo;
+    const uint32_t* sc_hi;
+    uint32_t sc_T;
+    uint32_t has_us;    // multiply stored value by uscale
+    uint32_t uscale;
+};
+
+__device__ __forceinline__ uint32_t rev_bits(uint32_t v, uint32_t bits) {
+    return bits ? (__brev(v) >> (32 - bits)) : 0u;
+}
+
+template <int LOG_R, int RR, bool DIF>
+__device__ __forceinline__ void radix_round(uint32_t* tile, const uint32_t* twl, uint32_t stride, uint32_t b,
+                                            uint32_t k0, uint32_t x, uint32_t g) {
+    constexpr uint32_t R = 1u << LOG_R;
+    constexpr uint32_t NSUB = 1u << (LOG_R - RR);
+    constexpr uint32_t SUB = 1u << RR;
+    const uint32_t lomask = (1u << k0) - 1u;
+    const uint32_t gspan = (1u << b) >> LOG_R;  // number of thread groups g
+    uint32_t v[R];
+    uint32_t base[NSUB], olo[NSUB];
+#pragma unroll
+    for (uint32_t js = 0; js < NSUB; js++) {
+        uint32_t o = js * gspan + g;
+        olo[js] = o & lomask;
+        base[js] = ((o >> k0) << (k0 + RR)) | olo[js];
+#pragma unroll
+        for (uint32_t ji = 0; ji < SUB; ji++) v[js * SUB + ji] = tile[(base[js] | (ji << k0)) * stride + x];
+    }
+#pragma unroll
+    for (uint32_t js = 0; js < NSUB; js++) {
+#pragma unroll
+        for (int uu = 0; uu < RR; uu++) {
+            const int u = DIF ? (RR - 1 - uu) : uu;
+            const uint32_t k = k0 + u;
+            const uint32_t tbase = (1u << k) - 1u + olo[js];
+#pragma unroll
+            for (uint32_t ji = 0; ji < SUB; ji++) {
+                if (ji & (1u << u)) continue;
+                const uint32_t j0 = js * SUB + ji, j1 = j0 | (1u << u);
+                const uint32_t w = twl[tbase + ((ji & ((1u << u) - 1u)) << k0)];
+                if (!DIF) {
+                    uint32_t t = bb::mul(v[j1], w);
+                    uint32_t a = v[j0];
+                    v[j0] = bb::add(a, t);
+                    v[j1] = bb::sub(a, t);
+                } else {
+                    uint32_t a = v[j0], c = v[j1];
+                    v[j0] = bb::add(a, c);
+                    v[j1] = bb::mul(bb::sub(a, c), w);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (uint32_t js = 0; js < NSUB; js++)
+#pragma unroll
+        for (uint32_t ji = 0; ji < SUB; ji++) tile[(base[js] | (ji << k0)) * stride + x] = v[js * SUB + ji];
+}
+
+template <int LOG_R, bool DIF>
+__device__ __forceinline__ void radix_round_dispatch(uint32_t rr, uint32_t* tile, const uint32_t* twl,
+                                                     uint32_t stride, uint32_t b, uint32_t k0, uint32_t x,
+                                                     uint32_t g) {
+    if constexpr (LOG_R >= 5) if (rr == 5) { radix_round<LOG_R, 5, DIF>(tile, twl, stride, b, k0, x, g); return; }
+    if constexpr (LOG_R >= 4) if (rr == 4) { radix_round<LOG_R, 4, DIF>(tile, twl, stride, b, k0, x, g); return; }
+    if constexpr (LOG_R >= 3) if (rr == 3) { radix_round<LOG_R, 3, DIF>(tile, twl, stride, b, k0, x, g); return; }
+    if constexpr (LOG_R >= 2) if (rr == 2) { radix_round<LOG_R, 2, DIF>(tile, twl, stride, b, k0, x, g); return; }
+    radix_round<LOG_R, 1, DIF>(tile, twl, stride, b, k0, x, g);
+}
+
+__device__ __forceinline__ uint32_t two_level(const uint32_t* lo, const uint32_t* hi, uint32_t T, uint64_t e) {
+    uint32_t l = lo[(uint32_t)e & ((1u << T) - 1u)];
+    uint32_t h = hi[(uint32_t)(e >> T)];
+    return bb::mul(l, h);
+}
+
+// Decodes a copy-loop index into tile coordinates (pt, x), the global word offset and the natural row
+// index for one side of the pass.  Returns false when the slot is padding (outside the matrix).
+template <uint32_t RUN>
+__device__ __forceinline__ bool decode_side(const PassArgs& a, uint32_t kind, uint32_t idx, uint32_t hi,
+                                            uint32_t h0, uint32_t c0, uint64_t f0, uint32_t& pt, uint32_t& x,
+                                            uint64_t& word, uint64_t& row, uint32_t& lo) {
+    const uint32_t b = a.b;
+    if (kind == SIDE_INPLACE) {
+        x = idx & (RUN - 1);
+        pt = idx >> __builtin_ctz(RUN);
+        uint64_t f = f0 + x;
+        uint64_t F = (uint64_t)a.W << a.s0;
+        if (f >= F) return false;
+        uint32_t c;
+        if (a.wshift != 0xffffffffu) { lo = (uint32_t)(f >> a.wshift); c = (uint32_t)f & (a.W - 1); }
+        else { lo = (uint32_t)(f / a.W); c = (uint32_t)(f - (uint64_t)lo * a.W); }
+        (void)c;
+        row = ((uint64_t)hi << (a.s0 + b)) + ((uint64_t)pt << a.s0) + lo;
+        word = (((uint64_t)hi << (a.s0 + b)) + ((uint64_t)pt << a.s0)) * a.W + f;
+        return true;
+    }
+    lo = 0;
+    uint32_t t, c;
+    const bool narrow = a.W < RUN;
+    if (narrow && kind != SIDE_STRIDED) {
+        // column-wise order: c fastest, then pt, then group t (contiguous global words within a group)
+        uint32_t q;
+        if (a.wshift != 0xffffffffu) { c = idx & (a.W - 1); q = idx >> a.wshift; }
+        else { q = idx / a.W; c = idx - q * a.W; }
+        pt = q & ((1u << b) - 1u);
+        t = q >> b;
+        if (t >= a.G) return false;
+        x = t * a.W + c;
+    } else {
+        x = idx & (RUN - 1);
+        pt = idx >> __builtin_ctz(RUN);
+        if (narrow) {
+            if (a.wshift != 0xffffffffu) { t = x >> a.wshift; c = x & (a.W - 1); }
+            else { t = x / a.W; c = x - t * a.W; }
+            if (t >= a.G) return false;
+        } else {
+            t = 0;
+            c = c0 + x;
+            if (c >= a.W) return false;
+        }
+    }
+    const uint32_t gbits = a.n - b;
+    const uint64_t ngroups = 1ull << gbits;
+    uint64_t h = (uint64_t)h0 + t;
+    if (h >= ngroups) return false;
+    if (kind == SIDE_STRIDED) row = ((uint64_t)rev_bits(pt, b) << gbits) + h;
+    else if (kind == SIDE_GROUP_REV) row = ((uint64_t)rev_bits((uint32_t)h, gbits) << b) + pt;
+    else row = (h << b) + pt;
+    word = row * a.W + c;
+    return true;
+}
+
+template <int LOG_RUN, int LOG_R>
+__global__ void __launch_bounds__(1024) ntt_pass_kernel(PassArgs a) {
+    constexpr uint32_t RUN = 1u << LOG_RUN, STRIDE = RUN + 1;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t b = a.b, npts = 1u << b;
+    uint32_t* tile = smem;
+    uint32_t* twl = smem + npts * STRIDE;
+    const uint32_t tid = threadIdx.x, nth = blockDim.x;
+    const uint32_t bid = blockIdx.x;
+
+    for (uint32_t i = tid; i + 1 < npts; i += nth) twl[i] = a.tile_tw[i];
+
+    uint32_t hi = 0, h0 = 0, c0 = 0;
+    uint64_t f0 = 0;
+    if (a.s0 == 0) {
+        if (a.W >= RUN) { h0 = bid / a.n_inner; c0 = (bid % a.n_inner) * RUN; }
+        else h0 = bid * a.G;
+    } else {
+        hi = bid / a.n_inner;
+        f0 = (uint64_t)(bid % a.n_inner) * RUN;
+    }
+
+    const uint32_t total = npts * RUN;
+    // ---- load ----
+    for (uint32_t idx = tid; idx < total; idx += nth) {
+        uint32_t pt, x, lo;
+        uint64_t word, row;
+        bool ok = decode_side<RUN>(a, a.load_kind, idx, hi, h0, c0, f0, pt, x, word, row, lo);
+        uint32_t v = 0;
+        if (ok) {
+            if (row < a.src_rows) {
+                v = a.src[word];
+                if (a.has_sc) v = bb::mul(v, two_level(a.sc_lo, a.sc_hi, a.sc_T, row));
+            }
+            if (a.has_tw && !a.dif)
+                v = bb::mul(v, two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)rev_bits(pt, b) * lo));
+            tile[pt * STRIDE + x] = v;
+        } else if (a.load_kind == SIDE_INPLACE || !(a.W < RUN && a.load_kind != SIDE_STRIDED)) {
+            // row-wise decode: (pt, x) are valid tile coordinates even for padding slots
+            tile[pt * STRIDE + x] = 0;
+        }
+    }
+    __syncthreads();
+
+    // ---- b stages as register-radix rounds ----
+    const uint32_t nwork = total >> LOG_R;
+    const uint32_t x = tid & (RUN - 1), g = tid >> LOG_RUN;
+    if (!a.dif) {
+        for (uint32_t k0 = 0; k0 < b;) {
+            uint32_t rr = (b - k0) < (uint32_t)LOG_R ? (b - k0) : (uint32_t)LOG_R;
+            if (tid < nwork) radix_round_dispatch<LOG_R, false>(rr, tile, twl, STRIDE, b, k0, x, g);
+            __syncthreads();
+            k0 += rr;
+        }
+    } else {
+        for (uint32_t top = b; top > 0;) {
+            uint32_t rr = top < (uint32_t)LOG_R ? top : (uint32_t)LOG_R;
+            if (tid < nwork) radix_round_dispatch<LOG_R, true>(rr, tile, twl, STRIDE, b, top - rr, x, g);
+            __syncthreads();
+            top -= rr;
+        }
+    }
+
+    // ---- store ----
+    for (uint32_t idx = tid; idx < total; idx += nth) {
+        uint32_t pt, xx, lo;
+        uint64_t word, row;
+        if (!decode_side<RUN>(a, a.store_kind, idx, hi, h0, c0, f0, pt, xx, word, row, lo)) continue;
+        uint32_t v = tile[pt * STRIDE + xx];
+        if (a.has_tw && a.dif)
+            v = bb::mul(v, two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)rev_bits(pt, b) * lo));
+        if (a.has_us) v = bb::mul(v, a.uscale);
+        a.dst[word] = v;
+    }
+}
+
+__global__ void bit_reverse_rows_kernel(const uint32_t* src, uint32_t* dst, uint32_t log_h, uint32_t W,
+                                        uint64_t total) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    uint64_t r = i / W;
+    uint32_t c = (uint32_t)(i - r * W);
+    uint64_t sr = log_h ? (uint64_t)(__brevll(r) >> (64 - log_h)) : 0;
+    dst[i] = src[sr * W + c];
+}
+
+int bit_reverse_rows(hipStream_t stream, const uint32_t* src, uint32_t* dst, uint64_t height, uint32_t width) {
+    uint64_t total = height * width;
+    if (!total) return OK;
+    if (!is_pow2(height)) return fail(ERR_BAD_ARG, "bit_reverse_rows: height must be a power of two");
+    uint32_t blocks = (uint32_t)((total + 255) / 256);
+    hipLaunchKernelGGL(bit_reverse_rows_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, log2u(height),
+                       width, total);
+    P3_HIP(hipGetLastError());
+    return OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side planning
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+constexpr uint32_t B_MAX = 11;
+
+// Digits, lowest position digit first.
+std::vector<uint32_t> split_digits(uint32_t n) {
+    std::vector<uint32_t> d;
+    if (n == 0) return d;
+    uint32_t passes = n <= B_MAX ? 1 : (n <= 2 * B_MAX ? 2 : 3);
+    uint32_t rem = n;
+    for (uint32_t i = 0; i < passes; i++) {
+        uint32_t b = (rem + (passes - i) - 1) / (passes - i);
+        d.push_back(b);
+        rem -= b;
+    }
+    return d;
+}
+
+template <int LOG_RUN, int LOG_R>
+int launch_pass_t(hipStream_t stream, const PassArgs& a, uint32_t blocks) {
+    constexpr uint32_t RUN = 1u << LOG_RUN;
+    uint32_t npts = 1u << a.b;
+    uint32_t threads = (npts * RUN) >> LOG_R;
+    if (threads < 64) threads = 64;
+    if (threads > 1024) return fail(ERR_INTERNAL, "ntt: tile needs more than 1024 threads");
+    size_t lds = (size_t)npts * (RUN + 1) * 4 + (size_t)npts * 4;
+    auto kern = ntt_pass_kernel<LOG_RUN, LOG_R>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        P3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, stream, a);
+    P3_HIP(hipGetLastError());
+    return OK;
+}
+
+int launch_pass(hipStream_t stream, PassArgs& a) {
+    // geometry
+    uint32_t log_run = a.b >= 11 ? 4 : 5;
+    uint32_t RUN = 1u << log_run;
+    a.wshift = is_pow2(a.W) ? log2u(a.W) : 0xffffffffu;
+    uint64_t blocks;
+    if (a.s0 == 0) {
+        uint64_t ngroups = 1ull << (a.n - a.b);
+        if (a.W >= RUN) {
+            a.G = 1;
+            a.n_inner = (a.W + RUN - 1) / RUN;
+            blocks = ngroups * a.n_inner;
+        } else {
+            a.G = RUN / a.W;
+            a.n_inner = 1;
+            blocks = (ngroups + a.G - 1) / a.G;
+        }
+    } else {
+        uint64_t F = (uint64_t)a.W << a.s0;
+        a.G = 1;
+        a.n_inner = (uint32_t)((F + RUN - 1) / RUN);
+        blocks = (1ull << (a.n - a.s0 - a.b)) * a.n_inner;
+    }
+    if (blocks > 0x7fffffffull) return fail(ERR_BAD_ARG, "ntt: matrix too large for one launch");
+    uint32_t nb = (uint32_t)blocks;
+    if (log_run == 4) return launch_pass_t<4, 5>(stream, a, nb);
+    uint32_t log_r = a.b >= 10 ? 5 : (a.b >= 4 ? 4 : a.b);
+    switch (log_r) {
+        case 5: return launch_pass_t<5, 5>(stream, a, nb);
+        case 4: return launch_pass_t<5, 4>(stream, a, nb);
+        case 3: return launch_pass_t<5, 3>(stream, a, nb);
+        case 2: return launch_pass_t<5, 2>(stream, a, nb);
+        default: return launch_pass_t<5, 1>(stream, a, nb);
+    }
+}
+
+int set_twiddle(Context& cx, PassArgs& a, bool inverse) {
+    a.has_tw = a.s0 > 0;
+    if (!a.has_tw) return OK;
+    TwoLevelTable t;
+    int rc = cx.get_root_table(a.s0 + a.b, inverse, &t);
+    if (rc) return rc;
+    a.tw_lo = t.lo; a.tw_hi = t.hi; a.tw_T = t.T;
+    return OK;
+}
+
+// DIT plan: natural in -> natural out.  uscale (if has_us) is applied by the last pass.
+int run_dit(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* dst, uint32_t n, uint32_t W,
+            bool inverse, bool has_us, uint32_t uscale) {
+    std::vector<uint32_t> digits = split_digits(n);
+    uint32_t s0 = 0;
+    for (size_t i = 0; i < digits.size(); i++) {
+        PassArgs a{};
+        a.W = W; a.n = n; a.b = digits[i]; a.s0 = s0; a.dif = 0;
+        a.tile_tw = cx.tile_tw[inverse ? 1 : 0];
+        a.src_rows = 1ull << n;
+        if (i == 0) { a.src = src; a.dst = dst; a.load_kind = SIDE_STRIDED; a.store_kind = SIDE_GROUP_REV; }
+        else { a.src = dst; a.dst = dst; a.load_kind = SIDE_INPLACE; a.store_kind = SIDE_INPLACE; }
+        int rc = set_twiddle(cx, a, inverse);
+        if (rc) return rc;
+        if (i + 1 == digits.size() && has_us) { a.has_us = 1; a.uscale = uscale; }
+        rc = launch_pass(stream, a);
+        if (rc) return rc;
+        s0 += digits[i];
+    }
+    return OK;
+}
+
+// DIF plan: natural in (first src_rows rows, zero padded to 2^n, optionally scaled per row) ->
+// bit-reversed (in place layout) or natural (scattered by the last pass) out.
+int run_dif(Context& cx, hipStream_t stream, const uint32_t* src, uint64_t src_rows, uint32_t* dst, uint32_t n,
+            uint32_t W, bool inverse, const TwoLevelTable* sc, bool natural_out) {
+    std::vector<uint32_t> digits = split_digits(n);  // lowest first; DIF walks them top-down
+    uint32_t s0 = n;
+    for (size_t ii = digits.size(); ii-- > 0;) {
+        bool first = ii + 1 == digits.size(), last = ii == 0;
+        s0 -= digits[ii];
+        PassArgs a{};
+        a.W = W; a.n = n; a.b = digits[ii]; a.s0 = s0; a.dif = 1;
+        a.tile_tw = cx.tile_tw[inverse ? 1 : 0];
+        a.src = first ? src : dst;
+        a.dst = dst;
+        a.src_rows = first ? src_rows : (1ull << n);
+        if (first && sc) { a.has_sc = 1; a.sc_lo = sc->lo; a.sc_hi = sc->hi; a.sc_T = sc->T; }
+        if (!last) { a.load_kind = SIDE_INPLACE; a.store_kind = SIDE_INPLACE; }
+        else if (natural_out) { a.load_kind = SIDE_GROUP_REV; a.store_kind = SIDE_STRIDED; }
+        else { a.load_kind = SIDE_GROUP; a.store_kind = SIDE_GROUP; }
+        int rc = set_twiddle(cx, a, inverse);
+        if (rc) return rc;
+        rc = launch_pass(stream, a);
+        if (rc) return rc;
+    }
+    return OK;
+}
+
+}  // namespace
+
+int ntt_dft(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* dst, uint64_t height,
+            uint32_t width, bool inverse) {
+    if (!height || !width) return OK;
+    if (!is_pow2(height)) return fail(ERR_BAD_ARG, "hip backend requires power-of-two height, got " + std::to_string(height));
+    uint32_t n = log2u(height);
+    if (n > bb::TWO_ADICITY) return fail(ERR_BAD_ARG, "height exceeds BabyBear two-adicity");
+    size_t bytes = height * width * 4;
+    if (n == 0) {
+        if (src != dst) P3_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream));
+        return OK;
+    }
+    if (src == dst) {  // the gathering first pass is out of place
+        int rc = cx.ws[0].reserve(bytes);
+        if (rc) return rc;
+        P3_HIP(hipMemcpyAsync(cx.ws[0].ptr, src, bytes, hipMemcpyDeviceToDevice, stream));
+        src = cx.ws[0].as<uint32_t>();
+    }
+    uint32_t hinv = inverse ? bb::inv(bb::to_monty((uint32_t)height)) : 0;
+    return run_dit(cx, stream, src, dst, n, width, inverse, inverse, hinv);
+}
+
+int ntt_coset_dft(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* dst, uint64_t height,
+                  uint32_t width, uint32_t shift) {
+    if (!height || !width) return OK;
+    if (!is_pow2(height)) return fail(ERR_BAD_ARG, "hip backend requires power-of-two height, got " + std::to_string(height));
+    uint32_t n = log2u(height);
+    if (n > bb::TWO_ADICITY) return fail(ERR_BAD_ARG, "height exceeds BabyBear two-adicity");
+    TwoLevelTable sc;
+    int rc = cx.get_scale_table(shift, n, bb::ONE, &sc);
+    if (rc) return rc;
+    if (n == 0) {  // single row: scale by shift^0 = 1
+        if (src != dst) P3_HIP(hipMemcpyAsync(dst, src, height * width * 4, hipMemcpyDeviceToDevice, stream));
+        return OK;
+    }
+    if (src == dst) return fail(ERR_BAD_ARG, "coset_dft: in-place not supported");
+    return run_dif(cx, stream, src, height, dst, n, width, false, &sc, true);
+}
+
+int ntt_coset_lde(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* dst, uint64_t height,
+                  uint32_t width, uint32_t added_bits, uint32_t shift, bool bit_reversed_out) {
+    if (!height || !width) return OK;
+    if (!is_pow2(height)) return fail(ERR_BAD_ARG, "hip backend requires power-of-two height, got " + std::to_string(height));
+    uint32_t n = log2u(height);
+    uint32_t m = n + added_bits;
+    if (m > bb::TWO_ADICITY) return fail(ERR_BAD_ARG, "LDE height exceeds BabyBear two-adicity");
+    if (src == dst) return fail(ERR_BAD_ARG, "coset_lde: in-place not supported");
+    size_t bytes = height * width * 4;
+    // 1. coefficients (natural order) into scratch: inverse DIT, 1/N folded into the scale table below
+    int rc = cx.ws[1].reserve(bytes);
+    if (rc) return rc;
+    uint32_t* coeffs = cx.ws[1].as<uint32_t>();
+    if (n == 0) P3_HIP(hipMemcpyAsync(coeffs, src, bytes, hipMemcpyDeviceToDevice, stream));
+    else {
+        rc = run_dit(cx, stream, src, coeffs, n, width, true, false, 0);
+        if (rc) return rc;
+    }
+    if (m == 0) {
+        P3_HIP(hipMemcpyAsync(dst, coeffs, bytes, hipMemcpyDeviceToDevice, stream));
+        return OK;
+    }
+    // 2. forward DIF over 2^m rows: rows >= height are zero, row j scaled by shift^j / N
+    TwoLevelTable sc;
+    uint32_t hinv = bb::inv(bb::to_monty((uint32_t)height));
+    rc = cx.get_scale_table(shift, n, hinv, &sc);
+    if (rc) return rc;
+    return run_dif(cx, stream, coeffs, height, dst, m, width, false, &sc, !bit_reversed_out);
+}
+
+}  // namespace p3

@@ -1,0 +1,155 @@
+"""GPU parity tests (MI355X): libp3hip NTT / coset-LDE through the C ABI vs the C oracle and the
+committed golden fixtures.  Bit-exact (integer arithmetic): every comparison is array_equal."""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+P = 0x78000001
+
+# reference benchmark shapes, native/src/fib_air.rs:103-117
+REF_SHAPES = [(256, 8), (1024, 8), (4096, 8), (16384, 8), (4096, 32), (16384, 32), (4096, 64), (4096, 128),
+              (16384, 64), (16384, 128), (256, 16000)]
+
+
+@pytest.fixture(scope="module")
+def dft(p3):
+    ok, msg = p3.is_available()
+    assert ok, msg
+    return p3.GpuDft.with_backend(p3.BackendKind.Hip)
+
+
+def _rand(rng, h, w):
+    return rng.integers(0, P, size=(h, w), dtype=np.uint64).astype(np.uint32)  # any word < P is a valid Monty residue
+
+
+def test_golden_dft_host_path(dft, oracle):
+    for case in golden("dft.json"):
+        if case["input"] == "benchmark_input":
+            x = oracle.benchmark_input(case["h"], case["w"])
+        else:
+            x = oracle.to_monty(np.array(case["input"], dtype=np.uint64))
+        got = dft.dft_batch(x)
+        assert np.array_equal(oracle.from_monty(got), np.array(case["out"], dtype=np.uint32)), (case["h"], case["w"])
+
+
+def test_golden_coset_lde_host_path(dft, oracle):
+    for case in golden("coset_lde.json"):
+        x = oracle.generate_trace_rows(0, 1, case["h"]) if case["input"] == "fib_trace" else \
+            oracle.benchmark_input(case["h"], case["w"])
+        sh = int(oracle.to_monty(case["shift"]))
+        exp = np.array(case["out"], dtype=np.uint32)
+        nat = dft.coset_lde_batch(x, case["added_bits"], sh)
+        assert np.array_equal(oracle.from_monty(nat), exp), case
+        br = dft.coset_lde_batch(x, case["added_bits"], sh, bit_reversed_out=True)
+        assert np.array_equal(oracle.bit_reverse_rows(br), nat), case
+
+
+@pytest.mark.parametrize("h,w", REF_SHAPES)
+def test_reference_benchmark_shapes(dft, oracle, h, w):
+    # the reference's own equality check, fib_air.rs:193-196, on its benchmark_input (fib_air.rs:77-86)
+    x = oracle.benchmark_input(h, w)
+    assert np.array_equal(dft.dft_batch(x), oracle.dft_batch(x))
+
+
+@pytest.mark.parametrize("log_h", list(range(0, 15)) + [16, 17])
+@pytest.mark.parametrize("w", [1, 2, 3, 4, 5, 8, 31, 32, 33, 70])
+def test_dft_all_heights_widths(dft, oracle, log_h, w):
+    if log_h >= 16 and w > 8:
+        pytest.skip("kept small")
+    rng = np.random.default_rng(log_h * 100 + w)
+    x = _rand(rng, 1 << log_h, w)
+    exp = oracle.dft_batch(x)
+    assert np.array_equal(dft.dft_batch(x), exp)
+    assert np.array_equal(dft.idft_batch(exp), x)
+
+
+@pytest.mark.parametrize("log_h,w,ab", [(0, 2, 1), (1, 2, 1), (3, 2, 1), (3, 2, 2), (5, 7, 3), (10, 2, 1), (11, 2, 1),
+                                        (12, 4, 1), (12, 2, 2), (13, 2, 3), (16, 2, 1), (16, 4, 2), (10, 40, 1),
+                                        (9, 2, 0)])
+def test_coset_lde_vs_oracle(dft, oracle, p3, log_h, w, ab):
+    rng = np.random.default_rng(7 * log_h + w + ab)
+    x = _rand(rng, 1 << log_h, w)
+    for shift in (p3.GENERATOR_MONTY, p3.MONTY_ONE, int(rng.integers(1, P))):
+        exp = oracle.coset_lde_batch(x, ab, shift)
+        assert np.array_equal(dft.coset_lde_batch(x, ab, shift), exp)
+        assert np.array_equal(dft.coset_lde_batch(x, ab, shift, bit_reversed_out=True), oracle.bit_reverse_rows(exp))
+        if ab == 0:
+            coeffs = oracle.idft_batch(x)
+            assert np.array_equal(dft.coset_dft_batch(coeffs, shift), oracle.coset_dft_batch(coeffs, shift))
+
+
+def test_device_resident_path_and_stream(dft, oracle, p3):
+    import torch
+    rng = np.random.default_rng(3)
+    x = _rand(rng, 1 << 14, 2)
+    xd = p3.dev_u32(x)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        yd = dft.dft_batch(xd)
+        ld = dft.coset_lde_batch(xd, 1, p3.GENERATOR_MONTY, bit_reversed_out=True)
+        back = dft.idft_batch(yd)
+    s.synchronize()
+    assert np.array_equal(p3.host_u32(yd), oracle.dft_batch(x))
+    assert np.array_equal(p3.host_u32(back), x)
+    assert np.array_equal(p3.host_u32(ld), oracle.coset_lde_batch(x, 1, p3.GENERATOR_MONTY, True))
+    assert np.array_equal(p3.host_u32(p3.bit_reverse_rows(ld)), oracle.coset_lde_batch(x, 1, p3.GENERATOR_MONTY))
+
+
+def test_fib_air_headline_size_properties(dft, oracle, p3):
+    """BASELINE cfg2: 2^20 x 2 fib trace, blowup 2.  Too big for the O(n log n) oracle to be quick in a
+    loop, so: one full oracle comparison, plus size-independent properties."""
+    import torch
+    n = 1 << 20
+    x = oracle.generate_trace_rows(0, 1, n)
+    xd = p3.dev_u32(x)
+    lde = dft.coset_lde_batch(xd, 1, p3.GENERATOR_MONTY, bit_reversed_out=True)
+    torch.cuda.synchronize()
+    got = p3.host_u32(lde)
+    assert np.array_equal(got, oracle.coset_lde_batch(x, 1, p3.GENERATOR_MONTY, True))
+    # round trip: idft(dft(x)) == x on device
+    assert torch.equal(dft.idft_batch(dft.dft_batch(xd)), xd)
+    # linearity: dft(a) + dft(b) == dft(a + b)  (mod P, Montgomery form is linear)
+    rng = np.random.default_rng(5)
+    a = _rand(rng, n, 2); b = _rand(rng, n, 2)
+    s = ((a.astype(np.uint64) + b) % P).astype(np.uint32)
+    fa, fb, fs = (p3.host_u32(dft.dft_batch(p3.dev_u32(v))) for v in (a, b, s))
+    assert np.array_equal(((fa.astype(np.uint64) + fb) % P).astype(np.uint32), fs)
+    # the LDE restricted to every 2nd natural-order point of the blown-up coset... shift=1: extends x itself
+    ext = p3.host_u32(dft.coset_lde_batch(xd, 1, p3.MONTY_ONE))
+    assert np.array_equal(ext[::2], x)
+
+
+def test_large_heights_round_trip(dft, p3):
+    """2^22 (two passes of 11) and 2^24 (three passes): inverse round trip + spot-check against a direct
+    evaluation of a sparse polynomial."""
+    import torch
+    for log_h in (22, 24):
+        n = 1 << log_h
+        g = torch.Generator(device="cuda").manual_seed(log_h)
+        xd = torch.randint(0, P, (n, 2), dtype=torch.int32, device="cuda", generator=g)
+        yd = dft.dft_batch(xd)
+        assert torch.equal(dft.idft_batch(yd), xd)
+        del yd
+        # delta at row r: dft[k] = x_r * w^(r k) -> column is a geometric sequence; check a few entries
+        r = 12345
+        d = torch.zeros((n, 2), dtype=torch.int32, device="cuda")
+        d[r, 0] = p3.MONTY_ONE
+        out = p3.host_u32(dft.dft_batch(d))
+        w = pow(pow(31, 15, P), 1 << (27 - log_h), P)
+        R = 1 << 32
+        for k in (0, 1, 2, 77777, n - 1):
+            assert int(out[k, 0]) == pow(w, r * k, P) * R % P
+            assert int(out[k, 1]) == 0
+
+
+def test_error_paths(dft, p3):
+    with pytest.raises(p3.P3HipError) as e:
+        dft.dft_batch(np.zeros((12, 2), np.uint32))
+    assert e.value.code == -1 and "power-of-two" in e.value.message
+    assert p3.take_last_error() is None  # take-and-clear
+    with pytest.raises(p3.P3HipError):
+        p3.GpuDft.with_backend(p3.BackendKind.Cpu).dft_batch(np.zeros((4, 2), np.uint32))
+    # empty matrices are a no-op
+    assert dft.dft_batch(np.zeros((0, 2), np.uint32)).shape == (0, 2)

@@ -1,0 +1,53 @@
+"""CPU tests of the host logic and of the C-ABI library surface (no compute calls: no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def test_library_exports_every_declared_symbol(p3):
+    hdr = open(os.path.join(ROOT, "include", "p3hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)  # prototypes only, not names mentioned in comments
+    declared = sorted(set(re.findall(r"\b(p3hip_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 25
+    lib = C.CDLL(p3._lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert set(p3._lib.declared_symbols()) == set(declared)
+
+
+def test_backend_selector_mirrors_reference(p3):
+    # gpu_dft.rs:53-63: case-insensitive names, unknown -> Err("unknown backend '...'")
+    try:
+        for name, kind in [("cpu", 0), ("VULKAN", 1), ("Metal", 2), ("webgpu", 3), ("hip", 4)]:
+            p3.set_backend_kind_from_str(name)
+            assert int(p3.get_backend_kind()) == kind
+        with pytest.raises(ValueError, match="unknown backend 'cuda'"):
+            p3.set_backend_kind_from_str("cuda")
+        assert int(p3.get_backend_kind()) == 4  # unchanged by the failed call
+        assert p3.take_last_error() is None  # the failed call's message was taken by the ValueError
+    finally:
+        p3.set_backend_kind_from_str("hip")
+    assert p3.GpuDft().backend == p3.BackendKind.Hip  # Default reads the global (gpu_dft.rs:76-83)
+
+
+def test_no_gpu_is_an_error_not_a_fallback(p3):
+    import numpy as np
+    ok, msg = p3.is_available()
+    if ok:
+        pytest.skip("GPU present")
+    assert msg.startswith("HIP unavailable")
+    with pytest.raises(p3.P3HipError):
+        p3.GpuDft.with_backend(p3.BackendKind.Hip).dft_batch(np.zeros((4, 2), np.uint32))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "plonky3-mobile_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cuh", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("test oracle", ""), os.path.join(dirpath, f)

@@ -85,6 +85,11 @@ int p3hip_coset_lde_batch_bb31_dev(const uint32_t *d_in, uint32_t *d_out, size_t
 /* write_bit_reversed_rows_u32 (backend_vulkan.rs:1005-1026) on device */
 int p3hip_bit_reverse_rows_dev(const uint32_t *d_in, uint32_t *d_out, size_t height, size_t width, void *stream);
 
+/* ---- FibonacciAir workload (native/src/fib_air.rs:224-306) --------------------------------------- */
+/* generate_trace_rows (fib_air.rs:266-284): n x 2 trace, row 0 = (a, b), row i = (right, left + right);
+ * n must be a power of two (fib_air.rs:267). */
+int p3hip_fib_trace_dev(uint64_t a, uint64_t b, size_t n, uint32_t *d_out, void *stream);
+
 /* ---- Poseidon2-BabyBear-16 (default_babybear_poseidon2_16, native/src/poseidon_cpu.rs:17-18) ----- */
 /* n independent width-16 states, in place. */
 int p3hip_poseidon2_permute_dev(uint32_t *d_states, size_t n, void *stream);

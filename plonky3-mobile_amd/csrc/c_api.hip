@@ -192,6 +192,18 @@ int p3hip_bit_reverse_rows_dev(const uint32_t* in, uint32_t* out, size_t h, size
     });
 }
 
+// ---- FibonacciAir workload ----------------------------------------------------------------------
+int p3hip_fib_trace_dev(uint64_t a, uint64_t b, size_t n, uint32_t* d_out, void* stream) {
+    return guarded([&]() -> int {
+        if (!n) return OK;
+        if (!d_out) return fail(ERR_BAD_ARG, "fib_trace: null output");
+        Context* cx;
+        int rc = get_context(&cx);
+        if (rc) return rc;
+        return fib_trace((hipStream_t)stream, a, b, n, d_out);
+    });
+}
+
 // ---- Poseidon2 ----------------------------------------------------------------------------------
 int p3hip_poseidon2_permute_dev(uint32_t* d_states, size_t n, void* stream) {
     return guarded([&]() -> int {

@@ -77,6 +77,9 @@ int ntt_coset_dft(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t
                   uint32_t width, uint32_t shift_monty);
 int bit_reverse_rows(hipStream_t stream, const uint32_t* src, uint32_t* dst, uint64_t height, uint32_t width);
 
+// ---- fib_air.hip ----
+int fib_trace(hipStream_t stream, uint64_t a, uint64_t b, uint64_t n, uint32_t* d_out);
+
 inline bool is_pow2(uint64_t v) { return v && !(v & (v - 1)); }
 inline uint32_t log2u(uint64_t v) {
     uint32_t l = 0;

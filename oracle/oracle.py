@@ -56,6 +56,7 @@ def lib():
         L.p3o_tree_layer_len.restype = C.c_size_t
         L.p3o_tree_layer_len.argtypes = [C.c_void_p, C.c_size_t]
         L.p3o_mmcs_free.argtypes = [C.c_void_p]
+        L.p3o_free.argtypes = [C.c_void_p]
     return _lib
 
 
@@ -202,6 +203,49 @@ def mmcs_verify_batch(root, dims, index, rows, path):
     path = _u32(path).reshape(-1, 8)
     return lib().p3o_mmcs_verify_batch(_p(_u32(root)), hs, ws, C.c_size_t(n), C.c_size_t(index),
                                        _p(rows), _p(path), C.c_size_t(path.shape[0])) == 0
+
+
+# ---- fib_air prover / verifier (stark.c) ----
+class FriParams:
+    """p3_fri::FriParameters; defaults = Plonky3's create_benchmark_fri_params (log_blowup 1,
+    log_final_poly_len 0, 100 queries, 16 proof-of-work bits) [UPSTREAM-RECALL]."""
+
+    def __init__(self, log_blowup=1, log_final_poly_len=0, num_queries=100, proof_of_work_bits=16):
+        self.log_blowup, self.log_final_poly_len = log_blowup, log_final_poly_len
+        self.num_queries, self.proof_of_work_bits = num_queries, proof_of_work_bits
+
+    def astuple(self):
+        return (self.log_blowup, self.log_final_poly_len, self.num_queries, self.proof_of_work_bits)
+
+
+def prove_fib_air(a, b, log_n, params=None):
+    params = params or FriParams()
+    out = C.POINTER(C.c_uint8)()
+    n = C.c_size_t()
+    L = lib()
+    rc = L.p3o_prove_fib_air(C.c_uint64(a), C.c_uint64(b), C.c_uint(log_n), *[C.c_uint(v) for v in params.astuple()],
+                             C.byref(out), C.byref(n))
+    if rc:
+        raise ValueError("oracle prove_fib_air: bad parameters")
+    data = C.string_at(out, n.value)
+    L.p3o_free(out)
+    return data
+
+
+def verify_fib_air(proof, a, b, x, log_n, params=None):
+    """0 = accept, otherwise the code of the failed check."""
+    params = params or FriParams()
+    buf = (C.c_uint8 * len(proof)).from_buffer_copy(proof)
+    return lib().p3o_verify_fib_air(buf, C.c_size_t(len(proof)), C.c_uint64(a), C.c_uint64(b), C.c_uint64(x),
+                                    C.c_uint(log_n), *[C.c_uint(v) for v in params.astuple()])
+
+
+def fib_public_x(a, b, n):
+    """canonical value of the last row's right column (the public value x, fib_air.rs:57,68)."""
+    l, r = a % P, b % P
+    for _ in range(n - 1):
+        l, r = r, (l + r) % P
+    return r
 
 
 # ---- workload generators (reference native/src/fib_air.rs) ----

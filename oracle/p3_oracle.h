@@ -58,6 +58,13 @@ int p3o_mmcs_verify_batch(const uint32_t root[8], const size_t *heights, const s
                           const uint32_t *path, size_t path_len);
 void p3o_mmcs_free(p3o_tree_t *t);
 
+/* ---- stark.c: fib_air prover / verifier (uni-stark + two-adic FRI PCS + duplex challenger) ---- */
+int p3o_prove_fib_air(uint64_t a, uint64_t b, unsigned log_n, unsigned log_blowup, unsigned log_final_poly_len,
+                      unsigned num_queries, unsigned pow_bits, uint8_t **out, size_t *out_len);
+int p3o_verify_fib_air(const uint8_t *proof, size_t len, uint64_t a, uint64_t b, uint64_t x_pub, unsigned log_n,
+                       unsigned log_blowup, unsigned log_final_poly_len, unsigned num_queries, unsigned pow_bits);
+void p3o_free(void *p);
+
 #ifdef __cplusplus
 }
 #endif

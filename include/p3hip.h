@@ -120,6 +120,30 @@ void p3hip_mmcs_free(p3hip_tree_t *tree);
 int p3hip_mmcs_commit(const uint32_t *const *mats, const size_t *heights, const size_t *widths,
                       size_t n_mats, uint32_t root_out[8], p3hip_tree_t **tree_out);
 
+/* ---- fib_air prover: p3_uni_stark::prove(&config, &FibonacciAir{}, trace, &pis) as called at
+ *      native/src/fib_air.rs:70, for StarkConfig<TwoAdicFriPcs<BabyBear, Dft, Poseidon2 Mmcs, ExtensionMmcs>,
+ *      BinomialExtensionField<BabyBear,4>, DuplexChallenger<BabyBear, Poseidon2-16, 16, 8>> ---------------- */
+typedef struct {
+    uint32_t log_blowup;          /* p3_fri::FriParameters::log_blowup */
+    uint32_t log_final_poly_len;  /* ::log_final_poly_len (create_test_fri_params(mmcs, 2) in fib_air.rs:62) */
+    uint32_t num_queries;
+    uint32_t proof_of_work_bits;
+} p3hip_fri_params_t;
+typedef struct p3hip_fib_prover p3hip_fib_prover_t;
+/* Allocates the prover's HBM arena for 2^log_n-row traces.  stream: hipStream_t to enqueue on, or pass
+ * own_stream != 0 to let the prover create (and own) a non-blocking stream — one prover per host thread. */
+int p3hip_fib_prover_create(unsigned log_n, const p3hip_fri_params_t *params, void *stream, int own_stream,
+                            p3hip_fib_prover_t **out);
+/* Proves the instance whose first trace row is (a, b) (generate_trace_rows(a, b, 2^log_n), public values
+ * [a, b, last right value], fib_air.rs:61,68).  The returned bytes stay valid until the next prove/destroy.
+ * Wire format: DESIGN.md "proof bytes". */
+int p3hip_fib_prover_prove(p3hip_fib_prover_t *prover, uint64_t a, uint64_t b, const uint8_t **proof_out,
+                           size_t *proof_len);
+/* host wall-clock per stage [trace commit, quotient commit, open, FRI commit phase, grind, queries] in ms,
+ * accumulated over *proofs proofs */
+int p3hip_fib_prover_stage_times(p3hip_fib_prover_t *prover, double out_ms[6], uint64_t *proofs, int reset);
+void p3hip_fib_prover_destroy(p3hip_fib_prover_t *prover);
+
 #ifdef __cplusplus
 }
 #endif

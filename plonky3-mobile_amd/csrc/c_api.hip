@@ -11,6 +11,7 @@
 #include "bb31.cuh"
 #include "common.h"
 #include "mmcs.h"
+#include "prover.h"
 
 namespace p3 {
 bool take_error(std::string* out);
@@ -309,5 +310,61 @@ int p3hip_mmcs_commit(const uint32_t* const* mats, const size_t* heights, const 
         return OK;
     });
 }
+
+}  // extern "C"
+
+// ---- fib_air prover (p3_uni_stark::prove as driven by native/src/fib_air.rs:60-70) ---------------
+struct p3hip_fib_prover {
+    FibProver prover;
+    std::vector<uint8_t> last;
+};
+
+extern "C" {
+
+int p3hip_fib_prover_create(unsigned log_n, const p3hip_fri_params_t* params, void* stream, int own_stream,
+                            p3hip_fib_prover_t** out) {
+    return guarded([&]() -> int {
+        if (!params || !out) return fail(ERR_BAD_ARG, "fib_prover_create: null argument");
+        Context* cx;
+        int rc = get_context(&cx);
+        if (rc) return rc;
+        hipStream_t st = (hipStream_t)stream;
+        bool own = false;
+        if (own_stream) {
+            P3_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            own = true;
+        }
+        std::unique_ptr<p3hip_fib_prover> p(new p3hip_fib_prover());
+        FriParams fp{params->log_blowup, params->log_final_poly_len, params->num_queries, params->proof_of_work_bits};
+        rc = p->prover.init(log_n, fp, st, own);
+        if (rc) return rc;
+        *out = p.release();
+        return OK;
+    });
+}
+
+int p3hip_fib_prover_prove(p3hip_fib_prover_t* prover, uint64_t a, uint64_t b, const uint8_t** proof_out,
+                           size_t* proof_len) {
+    return guarded([&]() -> int {
+        if (!prover || !proof_out || !proof_len) return fail(ERR_BAD_ARG, "fib_prover_prove: null argument");
+        int rc = prover->prover.prove(a, b, &prover->last);
+        if (rc) return rc;
+        *proof_out = prover->last.data();
+        *proof_len = prover->last.size();
+        return OK;
+    });
+}
+
+int p3hip_fib_prover_stage_times(p3hip_fib_prover_t* prover, double out_ms[6], uint64_t* proofs, int reset) {
+    if (!prover || !out_ms) return fail(ERR_BAD_ARG, "fib_prover_stage_times: null argument");
+    const StageTimes& t = prover->prover.times();
+    out_ms[0] = t.trace_commit_ms; out_ms[1] = t.quotient_commit_ms; out_ms[2] = t.open_ms;
+    out_ms[3] = t.fri_commit_ms; out_ms[4] = t.grind_ms; out_ms[5] = t.query_ms;
+    if (proofs) *proofs = t.proofs;
+    if (reset) prover->prover.reset_times();
+    return OK;
+}
+
+void p3hip_fib_prover_destroy(p3hip_fib_prover_t* prover) { delete prover; }
 
 }  // extern "C"

@@ -177,13 +177,13 @@ static RowSet make_rowset(const Tree& t, uint64_t h) {
 }
 
 Tree::~Tree() {
-    if (layers) (void)hipFree(layers);
+    if (layers && owns_layers) (void)hipFree(layers);
     if (staging) (void)hipFree(staging);
     for (void* p : owned) (void)hipFree(p);
 }
 
 int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t* heights, const size_t* widths,
-                size_t n_mats, Tree** out) {
+                size_t n_mats, Tree** out, uint32_t* ext_layers) {
     if (!n_mats || !d_mats || !heights || !widths || !out) return fail(ERR_BAD_ARG, "mmcs_commit: null/empty argument");
     if (n_mats > 64) return fail(ERR_BAD_ARG, "mmcs_commit: at most 64 matrices per commitment");
     uint64_t maxh = 0;
@@ -206,8 +206,8 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
     for (size_t i = 0; i < n_mats; i++) staging_words += widths[i];
     staging_words += (size_t)t->log_max_height * 8 + 8;
     t->staging_words = staging_words;
-    P3_HIP(hipMalloc(reinterpret_cast<void**>(&t->layers), total_digests * 32));
-    P3_HIP(hipMalloc(reinterpret_cast<void**>(&t->staging), staging_words * 4));
+    if (ext_layers) { t->layers = ext_layers; t->owns_layers = false; }
+    else P3_HIP(hipMalloc(reinterpret_cast<void**>(&t->layers), total_digests * 32));
     size_t off = 0;
     for (uint64_t len = maxh; len >= 1; len >>= 1) {
         t->layer_off.push_back(off);
@@ -248,8 +248,10 @@ int mmcs_root(hipStream_t stream, const Tree& t, uint32_t root_out[8]) {
     return OK;
 }
 
-int mmcs_open(hipStream_t stream, const Tree& t, uint64_t index, uint32_t* rows_out, uint32_t* path_out) {
+int mmcs_open(hipStream_t stream, const Tree& tc, uint64_t index, uint32_t* rows_out, uint32_t* path_out) {
+    Tree& t = const_cast<Tree&>(tc);
     if (index >> t.log_max_height) return fail(ERR_BAD_ARG, "mmcs_open: index out of range");
+    if (!t.staging) P3_HIP(hipMalloc(reinterpret_cast<void**>(&t.staging), t.staging_words * 4));
     OpenArgs a{};
     a.n_mats = (uint32_t)t.mats.size();
     a.log_max_height = t.log_max_height;

@@ -1,0 +1,36 @@
+// fib_air prover object: one instance owns its HBM arena and stream, reusable across proofs.
+#pragma once
+#include <chrono>
+#include <vector>
+
+#include "common.h"
+
+namespace p3 {
+
+// p3_fri::FriParameters (the mmcs field is implied: ExtensionMmcs over the Poseidon2 tree)
+struct FriParams {
+    uint32_t log_blowup, log_final_poly_len, num_queries, proof_of_work_bits;
+};
+
+struct StageTimes {  // host wall clock per stage, accumulated over `proofs`
+    double trace_commit_ms = 0, quotient_commit_ms = 0, open_ms = 0, fri_commit_ms = 0, grind_ms = 0, query_ms = 0;
+    uint64_t proofs = 0;
+};
+
+class FibProver {
+  public:
+    FibProver();
+    ~FibProver();
+    FibProver(const FibProver&) = delete;
+    int init(uint32_t log_n, const FriParams& fp, hipStream_t stream, bool own_stream);
+    // proves the FibonacciAir instance with first row (a, b); public values [a, b, last right value]
+    int prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof);
+    const StageTimes& times() const;
+    void reset_times();
+
+  private:
+    struct Impl;
+    Impl* im;
+};
+
+}  // namespace p3

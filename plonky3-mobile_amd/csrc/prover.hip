@@ -1,0 +1,663 @@
+// fib_air STARK prover on gfx950: everything O(N) stays in HBM; the host only runs the transcript.
+//
+// Stands in for the call chain the reference drives at native/src/fib_air.rs:60-70
+//   p3_uni_stark::prove -> TwoAdicFriPcs::{commit, open} -> p3_fri::prove (commit phase, grind, queries)
+// instantiated as north_star asks (BabyBear, Poseidon2 MMCS + DuplexChallenger<_, Perm16, 16, 8>, non-hiding).
+// Device: trace (fib_air.hip), coset LDEs (ntt.hip), Merkle trees (mmcs.hip) and the kernels below:
+//   selectors table, quotient values, inverse denominators 1/(z - x), barycentric openings,
+//   reduced (DEEP) openings, FRI folds, proof-of-work search, batched query gathers.
+// Host (this file): DuplexChallenger (a handful of permutations per proof), parameter bookkeeping,
+//   proof serialisation.  Wire format: u32 LE Montgomery words, u32 vector counts, Plonky3 struct order.
+// All of these passes are HBM- or integer-VALU-bound element-wise / reduction kernels: one lane per row,
+// 16-byte accesses, no MFMA.
+#include <memory>
+#include <cstring>
+
+#include "bb31.cuh"
+#include "common.h"
+#include "mmcs.h"
+#include "poseidon2.cuh"
+#include "prover.h"
+
+namespace p3 {
+
+using bb::Ext;
+
+// ------------------------------------------------------------------------------------------------
+// host: DuplexChallenger<BabyBear, Poseidon2-16, WIDTH 16, RATE 8>
+// ------------------------------------------------------------------------------------------------
+struct Challenger {
+    uint32_t state[16] = {0}, in[8] = {0}, out[8] = {0};
+    int n_in = 0, n_out = 0;
+    void duplex() {
+        for (int i = 0; i < n_in; i++) state[i] = in[i];
+        n_in = 0;
+        p2::permute(state);
+        memcpy(out, state, 32);
+        n_out = 8;
+    }
+    void observe(uint32_t v) {
+        n_out = 0;
+        in[n_in++] = v;
+        if (n_in == 8) duplex();
+    }
+    void observe_n(const uint32_t* v, size_t n) { for (size_t i = 0; i < n; i++) observe(v[i]); }
+    void observe_ext(const Ext& e) { observe_n(e.c, 4); }
+    uint32_t sample() {
+        if (n_in || !n_out) duplex();
+        return out[--n_out];
+    }
+    Ext sample_ext() { Ext r; for (int i = 0; i < 4; i++) r.c[i] = sample(); return r; }
+    size_t sample_bits(unsigned bits) { return (size_t)bb::from_monty(sample()) & (((size_t)1 << bits) - 1); }
+    bool check_witness(unsigned bits, uint32_t w) { observe(w); return sample_bits(bits) == 0; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// device kernels
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t tl(const TwoLevelTable& t, uint32_t e) {
+    return bb::mul(t.lo[e & ((1u << t.T) - 1u)], t.hi[e >> t.T]);
+}
+__device__ __forceinline__ uint32_t brev(uint32_t v, uint32_t bits) { return bits ? (__brev(v) >> (32 - bits)) : 0u; }
+
+__device__ __forceinline__ Ext ld_ext(const uint32_t* p) {
+    uint4 v = *reinterpret_cast<const uint4*>(p);
+    return Ext{{v.x, v.y, v.z, v.w}};
+}
+__device__ __forceinline__ void st_ext(uint32_t* p, const Ext& e) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(e.c[0], e.c[1], e.c[2], e.c[3]);
+}
+
+// selectors_on_coset for the trace domain <g_n> evaluated on GENERATOR*<g_n> (quotient degree 1):
+// sel[i] = (Z_H/(x_i - 1), Z_H/(x_i - g^-1)), x_i = 31 g^i.  Depends only on log_n: cached per context.
+// One lane inverts 2*SEL_CHUNK values with Montgomery's trick.
+constexpr int SEL_CHUNK = 8;
+__global__ void selectors_kernel(TwoLevelTable roots, uint32_t n, uint32_t gen, uint32_t ginv, uint32_t zh, uint2* sel) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t i0 = t * SEL_CHUNK;
+    if (i0 >= n) return;
+    uint32_t v[2 * SEL_CHUNK], pre[2 * SEL_CHUNK];
+    uint32_t acc = bb::ONE;
+#pragma unroll
+    for (int k = 0; k < SEL_CHUNK; k++) {
+        uint32_t x = bb::mul(gen, tl(roots, (i0 + k) & (n - 1)));
+        v[2 * k] = bb::sub(x, bb::ONE);
+        v[2 * k + 1] = bb::sub(x, ginv);
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * SEL_CHUNK; k++) { pre[k] = acc; acc = bb::mul(acc, v[k]); }
+    uint32_t inv = bb::mul(bb::inv(acc), zh);
+#pragma unroll
+    for (int k = 2 * SEL_CHUNK - 1; k >= 0; k--) {
+        uint32_t r = bb::mul(inv, pre[k]);
+        inv = bb::mul(inv, v[k]);
+        v[k] = r;
+    }
+#pragma unroll
+    for (int k = 0; k < SEL_CHUNK; k++)
+        if (i0 + k < n) sel[i0 + k] = make_uint2(v[2 * k], v[2 * k + 1]);
+}
+
+// quotient_values for FibonacciAir (fib_air.rs:232-264), natural order out (n x 4 base words).
+struct QuotArgs {
+    const uint2* lde;   // committed trace LDE, bit-reversed rows; first n rows = the quotient domain
+    const uint2* sel;
+    uint32_t* out;
+    TwoLevelTable roots;  // w_n^i
+    uint32_t n, log_n, gen, ginv, zh_inv;
+    uint32_t pis[3];
+    Ext apow[5];          // alpha^0..alpha^4
+};
+__global__ void __launch_bounds__(256) fib_quotient_kernel(QuotArgs a) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    uint2 loc = a.lde[brev(i, a.log_n)];
+    uint2 nxt = a.lde[brev((i + 1) & (a.n - 1), a.log_n)];
+    uint2 s = a.sel[i];
+    uint32_t x = bb::mul(a.gen, tl(a.roots, i));
+    uint32_t trans = bb::sub(x, a.ginv);
+    uint32_t c0 = bb::mul(s.x, bb::sub(loc.x, a.pis[0]));
+    uint32_t c1 = bb::mul(s.x, bb::sub(loc.y, a.pis[1]));
+    uint32_t c2 = bb::mul(trans, bb::sub(loc.y, nxt.x));
+    uint32_t c3 = bb::mul(trans, bb::sub(bb::add(loc.x, loc.y), nxt.y));
+    uint32_t c4 = bb::mul(s.y, bb::sub(loc.y, a.pis[2]));
+    Ext acc = bb::scale(a.apow[4], c0);
+    acc = bb::add(acc, bb::scale(a.apow[3], c1));
+    acc = bb::add(acc, bb::scale(a.apow[2], c2));
+    acc = bb::add(acc, bb::scale(a.apow[1], c3));
+    acc = bb::add(acc, bb::scale(a.apow[0], c4));
+    st_ext(a.out + 4 * (size_t)i, bb::scale(acc, a.zh_inv));
+}
+
+// compute_inverse_denominators: d0[j] = 1/(z0 - x_j), d1[j] = 1/(z1 - x_j), x_j = 31 g_big^bitrev(j),
+// over the whole LDE domain in committed (bit-reversed) order.  One lane batch-inverts 2*DEN_CHUNK values.
+constexpr int DEN_CHUNK = 4;
+__global__ void __launch_bounds__(256) inv_denoms_kernel(TwoLevelTable roots, uint32_t big, uint32_t log_big, uint32_t gen,
+                                                         Ext z0, Ext z1, uint32_t* d0, uint32_t* d1) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t j0 = t * DEN_CHUNK;
+    if (j0 >= big) return;
+    Ext v[2 * DEN_CHUNK], pre[2 * DEN_CHUNK];
+#pragma unroll
+    for (int k = 0; k < DEN_CHUNK; k++) {
+        uint32_t x = bb::mul(gen, tl(roots, brev((j0 + k) & (big - 1), log_big)));
+        v[2 * k] = z0; v[2 * k].c[0] = bb::sub(z0.c[0], x);
+        v[2 * k + 1] = z1; v[2 * k + 1].c[0] = bb::sub(z1.c[0], x);
+    }
+    Ext acc = bb::ext_one();
+#pragma unroll
+    for (int k = 0; k < 2 * DEN_CHUNK; k++) { pre[k] = acc; acc = bb::mul(acc, v[k]); }
+    Ext inv = bb::inv(acc);
+#pragma unroll
+    for (int k = 2 * DEN_CHUNK - 1; k >= 0; k--) {
+        Ext r = bb::mul(inv, pre[k]);
+        inv = bb::mul(inv, v[k]);
+        v[k] = r;
+    }
+#pragma unroll
+    for (int k = 0; k < DEN_CHUNK; k++) {
+        if (j0 + k >= big) break;
+        st_ext(d0 + 4 * (size_t)(j0 + k), v[2 * k]);
+        st_ext(d1 + 4 * (size_t)(j0 + k), v[2 * k + 1]);
+    }
+}
+
+// interpolate_coset (barycentric) for all three openings at once: partial sums over the low coset
+//   acc[0..1] += x d0 trace[j][c],  acc[2..3] += x d1 trace[j][c],  acc[4..7] += x d0 quot[j][c]
+// written per workgroup; the host adds the partials and applies (z^n - s^n)/(n s^n).
+constexpr int BARY_BLOCK = 256;
+__global__ void __launch_bounds__(BARY_BLOCK) barycentric_kernel(TwoLevelTable roots, uint32_t n, uint32_t log_big,
+                                                                 uint32_t gen, const uint2* lde_t, const uint4* lde_q,
+                                                                 const uint32_t* d0, const uint32_t* d1,
+                                                                 uint32_t* partials) {
+    Ext acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = bb::ext_zero();
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        uint32_t x = bb::mul(gen, tl(roots, brev(j, log_big)));
+        Ext e0 = bb::scale(ld_ext(d0 + 4 * (size_t)j), x);
+        Ext e1 = bb::scale(ld_ext(d1 + 4 * (size_t)j), x);
+        uint2 t = lde_t[j];
+        uint4 q = lde_q[j];
+        acc[0] = bb::add(acc[0], bb::scale(e0, t.x));
+        acc[1] = bb::add(acc[1], bb::scale(e0, t.y));
+        acc[2] = bb::add(acc[2], bb::scale(e1, t.x));
+        acc[3] = bb::add(acc[3], bb::scale(e1, t.y));
+        acc[4] = bb::add(acc[4], bb::scale(e0, q.x));
+        acc[5] = bb::add(acc[5], bb::scale(e0, q.y));
+        acc[6] = bb::add(acc[6], bb::scale(e0, q.z));
+        acc[7] = bb::add(acc[7], bb::scale(e0, q.w));
+    }
+    __shared__ uint32_t red[BARY_BLOCK / 64][32];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            uint32_t v = acc[k].c[c];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v = bb::add(v, (uint32_t)__shfl_down((int)v, off, 64));
+            if (lane == 0) red[wave][4 * k + c] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int w = 0; w < BARY_BLOCK / 64; w++) v = bb::add(v, red[w][threadIdx.x]);
+        partials[blockIdx.x * 32 + threadIdx.x] = v;
+    }
+}
+
+// reduced openings over the LDE domain (TwoAdicFriPcs::open):
+//   ro[j] = (ry0 - rt) d0 + alpha^2 (ry1 - rt) d1 + alpha^4 (ry2 - rq) d0,
+//   rt = sum_c alpha^c trace[j][c], rq = sum_c alpha^c quot[j][c].
+struct ReducedArgs {
+    const uint2* lde_t;
+    const uint4* lde_q;
+    const uint32_t* d0;
+    const uint32_t* d1;
+    uint32_t* ro;
+    uint32_t big;
+    Ext alp[5];  // alpha^0..alpha^4
+    Ext ry0, ry1, ry2;
+};
+__global__ void __launch_bounds__(256) reduced_openings_kernel(ReducedArgs a) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.big) return;
+    uint2 t = a.lde_t[j];
+    uint4 q = a.lde_q[j];
+    Ext rt = bb::scale(a.alp[1], t.y);
+    rt.c[0] = bb::add(rt.c[0], t.x);
+    Ext rq = bb::scale(a.alp[1], q.y);
+    rq.c[0] = bb::add(rq.c[0], q.x);
+    rq = bb::add(rq, bb::scale(a.alp[2], q.z));
+    rq = bb::add(rq, bb::scale(a.alp[3], q.w));
+    Ext e0 = ld_ext(a.d0 + 4 * (size_t)j), e1 = ld_ext(a.d1 + 4 * (size_t)j);
+    Ext r = bb::mul(bb::add(bb::sub(a.ry0, rt), bb::mul(a.alp[4], bb::sub(a.ry2, rq))), e0);
+    r = bb::add(r, bb::mul(bb::mul(a.alp[2], bb::sub(a.ry1, rt)), e1));
+    st_ext(a.ro + 4 * (size_t)j, r);
+}
+
+// TwoAdicFriFolding::fold_matrix: out[i] = (lo + hi)/2 + (beta/2) g^-bitrev(i) (lo - hi)
+__global__ void __launch_bounds__(256) fri_fold_kernel(TwoLevelTable inv_roots /* w_len^-e */, const uint32_t* in,
+                                                       uint32_t* out, uint32_t half, uint32_t log_half, Ext half_beta,
+                                                       uint32_t one_half) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+    Ext lo = ld_ext(in + 8 * (size_t)i), hi = ld_ext(in + 8 * (size_t)i + 4);
+    uint32_t p = tl(inv_roots, brev(i, log_half));
+    Ext s = bb::scale(bb::add(lo, hi), one_half);
+    Ext d = bb::mul(bb::scale(half_beta, p), bb::sub(lo, hi));
+    st_ext(out + 4 * (size_t)i, bb::add(s, d));
+}
+
+// GrindingChallenger::grind: smallest canonical w with sample_bits(bits) == 0 after observe(w).
+__global__ void __launch_bounds__(256) grind_kernel(const uint32_t* state16, uint32_t pos, uint32_t mask, uint32_t base,
+                                                    uint32_t* result) {
+    uint32_t w = base + blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= bb::P) return;
+    uint32_t s[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = state16[i];
+    uint32_t wm = bb::to_monty(w);
+#pragma unroll
+    for (int i = 0; i < 8; i++) s[i] = (i == (int)pos) ? wm : s[i];
+    p2::permute(s);
+    if ((bb::from_monty(s[7]) & mask) == 0) atomicMin(result, w);
+}
+
+// Batched Mmcs::open_batch for the query phase: block (q, t) copies tree t's opened row and sibling path
+// for query q into its fixed slot of the staging buffer.
+struct QTree {
+    const uint32_t* mat;
+    const uint32_t* layers;
+    uint32_t width, log_height, shift, slot_off;  // index used = query_index >> shift; slot_off in words
+};
+__global__ void query_gather_kernel(const QTree* trees, uint32_t n_trees, const uint32_t* indices, uint32_t slot_words,
+                                    uint32_t* out) {
+    const QTree t = trees[blockIdx.y];
+    uint64_t index = indices[blockIdx.x] >> t.shift;
+    uint32_t* dst = out + (size_t)blockIdx.x * slot_words + t.slot_off;
+    for (uint32_t c = threadIdx.x; c < t.width; c += blockDim.x) dst[c] = t.mat[index * t.width + c];
+    uint64_t base = 0, len = 1ull << t.log_height;
+    for (uint32_t i = 0; i < t.log_height; i++) {
+        uint64_t sib = (index >> i) ^ 1;
+        if (threadIdx.x < 8) dst[t.width + i * 8 + threadIdx.x] = t.layers[base + sib * 8 + threadIdx.x];
+        base += len * 8;
+        len >>= 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host orchestration
+// ------------------------------------------------------------------------------------------------
+static void put_u32(std::vector<uint8_t>& b, uint32_t v) {
+    size_t o = b.size();
+    b.resize(o + 4);
+    memcpy(b.data() + o, &v, 4);
+}
+static void put_words(std::vector<uint8_t>& b, const uint32_t* w, size_t n) {
+    size_t o = b.size();
+    b.resize(o + 4 * n);
+    memcpy(b.data() + o, w, 4 * n);
+}
+
+struct FibProver::Impl {
+    uint32_t log_n = 0, log_big = 0;
+    FriParams fp{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // arena
+    uint32_t *trace = nullptr, *lde_t = nullptr, *qflat = nullptr, *lde_q = nullptr, *d0 = nullptr, *d1 = nullptr;
+    uint32_t *layers_t = nullptr, *layers_q = nullptr, *fri_vec = nullptr, *fri_layers = nullptr;
+    uint32_t *partials = nullptr, *small = nullptr, *qstage = nullptr, *qidx = nullptr;
+    QTree* qtrees = nullptr;
+    uint32_t* host_pinned = nullptr;  // pinned staging for small D2H reads
+    size_t host_pinned_words = 0;
+    std::vector<void*> allocs;
+    uint32_t n_rounds = 0;
+    std::vector<size_t> fri_vec_off, fri_layer_off;  // word offsets per round
+    size_t slot_words = 0;
+    uint32_t bary_blocks = 0;
+    StageTimes times{};
+    ~Impl() {
+        for (void* p : allocs) (void)hipFree(p);
+        if (host_pinned) (void)hipHostFree(host_pinned);
+        if (own_stream && stream) (void)hipStreamDestroy(stream);
+    }
+    int alloc(uint32_t** p, size_t words) {
+        P3_HIP(hipMalloc(reinterpret_cast<void**>(p), words * 4 + 64));
+        allocs.push_back(*p);
+        return OK;
+    }
+};
+
+FibProver::FibProver() : im(new Impl()) {}
+FibProver::~FibProver() { delete im; }
+
+int FibProver::init(uint32_t log_n, const FriParams& fp, hipStream_t stream, bool own_stream) {
+    Impl& s = *im;
+    if (log_n < 1) return fail(ERR_BAD_ARG, "fib prover: log_n must be >= 1");
+    if (log_n + fp.log_blowup > bb::TWO_ADICITY || log_n + fp.log_blowup > 31)
+        return fail(ERR_BAD_ARG, "fib prover: LDE height exceeds two-adicity");
+    if (fp.log_blowup < 1) return fail(ERR_BAD_ARG, "fib prover: log_blowup must be >= 1");
+    if (fp.log_final_poly_len > log_n) return fail(ERR_BAD_ARG, "fib prover: final polynomial longer than the trace");
+    if (fp.proof_of_work_bits > 30) return fail(ERR_BAD_ARG, "fib prover: proof_of_work_bits too large");
+    s.log_n = log_n; s.fp = fp; s.log_big = log_n + fp.log_blowup;
+    s.stream = stream; s.own_stream = own_stream;
+    const size_t n = (size_t)1 << log_n, big = (size_t)1 << s.log_big;
+    int rc;
+    if ((rc = s.alloc(&s.trace, n * 2))) return rc;
+    if ((rc = s.alloc(&s.lde_t, big * 2))) return rc;
+    if ((rc = s.alloc(&s.qflat, n * 4))) return rc;
+    if ((rc = s.alloc(&s.lde_q, big * 4))) return rc;
+    if ((rc = s.alloc(&s.d0, big * 4))) return rc;
+    if ((rc = s.alloc(&s.d1, big * 4))) return rc;
+    if ((rc = s.alloc(&s.layers_t, mmcs_layer_words(big)))) return rc;
+    if ((rc = s.alloc(&s.layers_q, mmcs_layer_words(big)))) return rc;
+    // FRI: vector r has big >> r ext elements; its commitment tree has (big >> (r+1)) leaves
+    s.n_rounds = s.log_big - fp.log_blowup - fp.log_final_poly_len;
+    size_t vec_words = 0, layer_words = 0;
+    for (uint32_t r = 0; r <= s.n_rounds; r++) { s.fri_vec_off.push_back(vec_words); vec_words += (big >> r) * 4; }
+    for (uint32_t r = 0; r < s.n_rounds; r++) { s.fri_layer_off.push_back(layer_words); layer_words += mmcs_layer_words(big >> (r + 1)); }
+    if ((rc = s.alloc(&s.fri_vec, vec_words))) return rc;
+    if ((rc = s.alloc(&s.fri_layers, layer_words + 8))) return rc;
+    s.bary_blocks = (uint32_t)std::min<size_t>(1024, (n + BARY_BLOCK - 1) / BARY_BLOCK);
+    if ((rc = s.alloc(&s.partials, (size_t)s.bary_blocks * 32))) return rc;
+    if ((rc = s.alloc(&s.small, 64))) return rc;
+    // query staging: per query one slot holding every tree's (row, path)
+    size_t slot = (2 + s.log_big * 8) + (4 + s.log_big * 8);
+    for (uint32_t r = 0; r < s.n_rounds; r++) slot += 8 + (size_t)(s.log_big - 1 - r) * 8;
+    s.slot_words = slot;
+    if ((rc = s.alloc(&s.qstage, slot * std::max<uint32_t>(fp.num_queries, 1)))) return rc;
+    if ((rc = s.alloc(&s.qidx, std::max<uint32_t>(fp.num_queries, 1)))) return rc;
+    uint32_t* qt = nullptr;
+    if ((rc = s.alloc(&qt, (sizeof(QTree) / 4) * (s.n_rounds + 2)))) return rc;
+    s.qtrees = reinterpret_cast<QTree*>(qt);
+    s.host_pinned_words = std::max<size_t>((size_t)s.bary_blocks * 32, slot * std::max<uint32_t>(fp.num_queries, 1)) + 64;
+    P3_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.host_pinned), s.host_pinned_words * 4));
+    // device descriptors of the trees opened per query (fixed for the prover's lifetime)
+    std::vector<QTree> qd;
+    uint32_t off = 0;
+    qd.push_back(QTree{s.lde_t, s.layers_t, 2, s.log_big, 0, off}); off += 2 + s.log_big * 8;
+    qd.push_back(QTree{s.lde_q, s.layers_q, 4, s.log_big, 0, off}); off += 4 + s.log_big * 8;
+    for (uint32_t r = 0; r < s.n_rounds; r++) {
+        uint32_t lh = s.log_big - 1 - r;
+        qd.push_back(QTree{s.fri_vec + s.fri_vec_off[r], s.fri_layers + s.fri_layer_off[r], 8, lh, r + 1, off});
+        off += 8 + lh * 8;
+    }
+    P3_HIP(hipMemcpy(s.qtrees, qd.data(), qd.size() * sizeof(QTree), hipMemcpyHostToDevice));
+    return OK;
+}
+
+// Cached per context: selector table for log_n.
+static int get_selectors(Context& cx, hipStream_t stream, uint32_t log_n, const uint2** out) {
+    static thread_local std::map<uint32_t, uint2*> cache;
+    auto it = cache.find(log_n);
+    if (it != cache.end()) { *out = it->second; return OK; }
+    const uint32_t n = 1u << log_n;
+    uint2* sel = nullptr;
+    P3_HIP(hipMalloc(reinterpret_cast<void**>(&sel), (size_t)n * 8));
+    TwoLevelTable roots;
+    int rc = cx.get_root_table(log_n, false, &roots);
+    if (rc) return rc;
+    uint32_t gen = bb::to_monty(bb::GEN);
+    uint32_t g = bb::two_adic_generator(log_n), ginv = bb::inv(g);
+    uint32_t zh = bb::sub(bb::pow(gen, n), bb::ONE);
+    uint32_t threads = (n + SEL_CHUNK - 1) / SEL_CHUNK;
+    hipLaunchKernelGGL(selectors_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, roots, n, gen, ginv, zh, sel);
+    P3_HIP(hipGetLastError());
+    P3_HIP(hipStreamSynchronize(stream));  // one-time: other streams of this thread may use the table next
+    cache[log_n] = sel;
+    *out = sel;
+    return OK;
+}
+
+static double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+int FibProver::prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof) {
+    Impl& s = *im;
+    Context* cxp;
+    int rc = get_context(&cxp);
+    if (rc) return rc;
+    Context& cx = *cxp;
+    hipStream_t st = s.stream;
+    const uint32_t log_n = s.log_n, log_big = s.log_big;
+    const uint32_t n = 1u << log_n, big = 1u << log_big;
+    const uint32_t gen = bb::to_monty(bb::GEN);
+    const uint32_t g_n = bb::two_adic_generator(log_n), g_n_inv = bb::inv(g_n);
+    double t0 = now_ms();
+
+    // ---- trace + commit (pcs.commit: bit-reversed coset LDE, shift GENERATOR) ----
+    if ((rc = fib_trace(st, a, b, n, s.trace))) return rc;
+    if ((rc = ntt_coset_lde(cx, st, s.trace, s.lde_t, n, 2, s.fp.log_blowup, gen, true))) return rc;
+    const uint32_t* mp[1] = {s.lde_t};
+    size_t hh[1] = {big}, ww[1] = {2};
+    Tree* tp = nullptr;
+    if ((rc = mmcs_commit(st, mp, hh, ww, 1, &tp, s.layers_t))) return rc;
+    std::unique_ptr<Tree> tree_t(tp);
+    // public values: first row and last right value
+    uint32_t* hp = s.host_pinned;
+    P3_HIP(hipMemcpyAsync(hp, tree_t->layers + tree_t->layer_off.back(), 32, hipMemcpyDeviceToHost, st));
+    P3_HIP(hipMemcpyAsync(hp + 8, s.trace, 8, hipMemcpyDeviceToHost, st));
+    P3_HIP(hipMemcpyAsync(hp + 10, s.trace + 2 * (size_t)(n - 1) + 1, 4, hipMemcpyDeviceToHost, st));
+    P3_HIP(hipStreamSynchronize(st));
+    uint32_t root_t[8], pis[3] = {hp[8], hp[9], hp[10]};
+    memcpy(root_t, hp, 32);
+    double t1 = now_ms();
+    Challenger ch;
+    ch.observe(bb::to_monty(log_n));
+    ch.observe(bb::to_monty(log_n));
+    ch.observe_n(root_t, 8);
+    ch.observe_n(pis, 3);
+    Ext alpha = ch.sample_ext();
+
+    // ---- quotient values + commit (shift GENERATOR/GENERATOR = 1) ----
+    const uint2* sel = nullptr;
+    if ((rc = get_selectors(cx, st, log_n, &sel))) return rc;
+    {
+        QuotArgs qa{};
+        qa.lde = reinterpret_cast<const uint2*>(s.lde_t);
+        qa.sel = sel;
+        qa.out = s.qflat;
+        if ((rc = cx.get_root_table(log_n, false, &qa.roots))) return rc;
+        qa.n = n; qa.log_n = log_n; qa.gen = gen; qa.ginv = g_n_inv;
+        qa.zh_inv = bb::inv(bb::sub(bb::pow(gen, n), bb::ONE));
+        memcpy(qa.pis, pis, 12);
+        qa.apow[0] = bb::ext_one();
+        for (int k = 1; k < 5; k++) qa.apow[k] = bb::mul(qa.apow[k - 1], alpha);
+        hipLaunchKernelGGL(fib_quotient_kernel, dim3((n + 255) / 256), dim3(256), 0, st, qa);
+        P3_HIP(hipGetLastError());
+    }
+    if ((rc = ntt_coset_lde(cx, st, s.qflat, s.lde_q, n, 4, s.fp.log_blowup, bb::ONE, true))) return rc;
+    mp[0] = s.lde_q; ww[0] = 4;
+    if ((rc = mmcs_commit(st, mp, hh, ww, 1, &tp, s.layers_q))) return rc;
+    std::unique_ptr<Tree> tree_q(tp);
+    uint32_t root_q[8];
+    P3_HIP(hipMemcpyAsync(hp, tree_q->layers + tree_q->layer_off.back(), 32, hipMemcpyDeviceToHost, st));
+    P3_HIP(hipStreamSynchronize(st));
+    memcpy(root_q, hp, 32);
+    double t2 = now_ms();
+    ch.observe_n(root_q, 8);
+    Ext zeta = ch.sample_ext();
+    Ext zeta_next = bb::scale(zeta, g_n);
+
+    // ---- pcs.open: opened values ----
+    TwoLevelTable roots_big;
+    if ((rc = cx.get_root_table(log_big, false, &roots_big))) return rc;
+    {
+        uint32_t threads = (big + DEN_CHUNK - 1) / DEN_CHUNK;
+        hipLaunchKernelGGL(inv_denoms_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, roots_big, big, log_big, gen,
+                           zeta, zeta_next, s.d0, s.d1);
+        P3_HIP(hipGetLastError());
+        hipLaunchKernelGGL(barycentric_kernel, dim3(s.bary_blocks), dim3(BARY_BLOCK), 0, st, roots_big, n, log_big, gen,
+                           reinterpret_cast<const uint2*>(s.lde_t), reinterpret_cast<const uint4*>(s.lde_q), s.d0, s.d1,
+                           s.partials);
+        P3_HIP(hipGetLastError());
+    }
+    P3_HIP(hipMemcpyAsync(hp, s.partials, (size_t)s.bary_blocks * 128, hipMemcpyDeviceToHost, st));
+    P3_HIP(hipStreamSynchronize(st));
+    Ext opened[8];
+    for (int k = 0; k < 8; k++) opened[k] = bb::ext_zero();
+    for (uint32_t blk = 0; blk < s.bary_blocks; blk++)
+        for (int k = 0; k < 8; k++)
+            for (int c = 0; c < 4; c++) opened[k].c[c] = bb::add(opened[k].c[c], hp[blk * 32 + 4 * k + c]);
+    {
+        uint32_t sn = bb::pow(gen, n);
+        uint32_t denom = bb::inv(bb::mul(bb::to_monty(n), sn));
+        Ext f0 = bb::scale(bb::sub(bb::pow(zeta, n), bb::ext_from_base(sn)), denom);
+        Ext f1 = bb::scale(bb::sub(bb::pow(zeta_next, n), bb::ext_from_base(sn)), denom);
+        for (int k = 0; k < 8; k++) opened[k] = bb::mul(opened[k], (k == 2 || k == 3) ? f1 : f0);
+    }
+    for (int k = 0; k < 8; k++) ch.observe_ext(opened[k]);
+    Ext al = ch.sample_ext();
+    double t3 = now_ms();
+
+    // ---- reduced openings -> FRI input ----
+    {
+        ReducedArgs ra{};
+        ra.lde_t = reinterpret_cast<const uint2*>(s.lde_t);
+        ra.lde_q = reinterpret_cast<const uint4*>(s.lde_q);
+        ra.d0 = s.d0; ra.d1 = s.d1; ra.ro = s.fri_vec + s.fri_vec_off[0]; ra.big = big;
+        ra.alp[0] = bb::ext_one();
+        for (int k = 1; k < 5; k++) ra.alp[k] = bb::mul(ra.alp[k - 1], al);
+        ra.ry0 = bb::add(opened[0], bb::mul(ra.alp[1], opened[1]));
+        ra.ry1 = bb::add(opened[2], bb::mul(ra.alp[1], opened[3]));
+        ra.ry2 = bb::add(bb::add(opened[4], bb::mul(ra.alp[1], opened[5])),
+                         bb::add(bb::mul(ra.alp[2], opened[6]), bb::mul(ra.alp[3], opened[7])));
+        hipLaunchKernelGGL(reduced_openings_kernel, dim3((big + 255) / 256), dim3(256), 0, st, ra);
+        P3_HIP(hipGetLastError());
+    }
+
+    // ---- FRI commit phase ----
+    std::vector<std::unique_ptr<Tree>> ftrees;
+    std::vector<uint32_t> froots((size_t)s.n_rounds * 8);
+    const uint32_t one_half = bb::inv(bb::to_monty(2));
+    for (uint32_t r = 0; r < s.n_rounds; r++) {
+        uint32_t len = big >> r, half = len >> 1;
+        mp[0] = s.fri_vec + s.fri_vec_off[r];
+        hh[0] = half; ww[0] = 8;  // ExtensionMmcs: rows of two ext elements, flattened
+        if ((rc = mmcs_commit(st, mp, hh, ww, 1, &tp, s.fri_layers + s.fri_layer_off[r]))) return rc;
+        ftrees.emplace_back(tp);
+        P3_HIP(hipMemcpyAsync(hp, tp->layers + tp->layer_off.back(), 32, hipMemcpyDeviceToHost, st));
+        P3_HIP(hipStreamSynchronize(st));
+        memcpy(&froots[(size_t)r * 8], hp, 32);
+        ch.observe_n(&froots[(size_t)r * 8], 8);
+        Ext beta = ch.sample_ext();
+        TwoLevelTable inv_roots;
+        uint32_t log_half = log_big - 1 - r;
+        if ((rc = cx.get_root_table(log_half + 1, true, &inv_roots))) return rc;
+        hipLaunchKernelGGL(fri_fold_kernel, dim3((half + 255) / 256), dim3(256), 0, st, inv_roots,
+                           s.fri_vec + s.fri_vec_off[r], s.fri_vec + s.fri_vec_off[r + 1], half, log_half,
+                           bb::scale(beta, one_half), one_half);
+        P3_HIP(hipGetLastError());
+    }
+    // final polynomial: first 2^lfp entries (bit-reversed order) -> natural order -> inverse DFT on the host
+    const uint32_t fpl = 1u << s.fp.log_final_poly_len;
+    std::vector<Ext> fpoly(fpl);
+    {
+        P3_HIP(hipMemcpyAsync(hp, s.fri_vec + s.fri_vec_off[s.n_rounds], (size_t)fpl * 16, hipMemcpyDeviceToHost, st));
+        P3_HIP(hipStreamSynchronize(st));
+        std::vector<Ext> ev(fpl);
+        for (uint32_t i = 0; i < fpl; i++) {
+            uint32_t j = 0;
+            for (uint32_t k = 0; k < s.fp.log_final_poly_len; k++) j |= ((i >> k) & 1u) << (s.fp.log_final_poly_len - 1 - k);
+            memcpy(ev[i].c, hp + 4 * (size_t)j, 16);
+        }
+        // naive inverse DFT (fpl is tiny): c_k = 1/fpl * sum_i ev_i w^-(ik)
+        uint32_t winv = bb::inv(bb::two_adic_generator(s.fp.log_final_poly_len));
+        uint32_t ninv = bb::inv(bb::to_monty(fpl));
+        for (uint32_t k = 0; k < fpl; k++) {
+            Ext acc = bb::ext_zero();
+            for (uint32_t i = 0; i < fpl; i++) acc = bb::add(acc, bb::scale(ev[i], bb::pow(winv, (uint64_t)i * k)));
+            fpoly[k] = bb::scale(acc, ninv);
+            ch.observe_ext(fpoly[k]);
+        }
+    }
+    double t4 = now_ms();
+
+    // ---- proof of work ----
+    uint32_t witness = 0;
+    {
+        Challenger c2 = ch;  // state with the pending inputs applied, witness slot = n_in
+        uint32_t pre[16];
+        memcpy(pre, c2.state, 64);
+        for (int i = 0; i < c2.n_in; i++) pre[i] = c2.in[i];
+        uint32_t pos = (uint32_t)c2.n_in;
+        memcpy(hp, pre, 64);
+        hp[16] = 0xffffffffu;
+        P3_HIP(hipMemcpyAsync(s.small, hp, 68, hipMemcpyHostToDevice, st));
+        uint32_t mask = (1u << s.fp.proof_of_work_bits) - 1u;
+        const uint32_t batch = 1u << 20;
+        uint32_t found = 0xffffffffu;
+        for (uint64_t base = 0; base < bb::P && found == 0xffffffffu; base += batch) {
+            hipLaunchKernelGGL(grind_kernel, dim3(batch / 256), dim3(256), 0, st, s.small, pos, mask, (uint32_t)base, s.small + 16);
+            P3_HIP(hipGetLastError());
+            P3_HIP(hipMemcpyAsync(hp + 32, s.small + 16, 4, hipMemcpyDeviceToHost, st));
+            P3_HIP(hipStreamSynchronize(st));
+            found = hp[32];
+        }
+        if (found == 0xffffffffu) return fail(ERR_INTERNAL, "grind: no proof-of-work witness found");
+        witness = bb::to_monty(found);
+        if (!ch.check_witness(s.fp.proof_of_work_bits, witness)) return fail(ERR_INTERNAL, "grind: witness rejected by the host challenger");
+    }
+    double t5 = now_ms();
+
+    // ---- query phase ----
+    const uint32_t nq = s.fp.num_queries;
+    std::vector<uint32_t> qidx(nq);
+    for (uint32_t q = 0; q < nq; q++) qidx[q] = (uint32_t)ch.sample_bits(log_big);
+    if (nq) {
+        memcpy(hp, qidx.data(), (size_t)nq * 4);
+        P3_HIP(hipMemcpyAsync(s.qidx, hp, (size_t)nq * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(query_gather_kernel, dim3(nq, s.n_rounds + 2), dim3(64), 0, st, s.qtrees, s.n_rounds + 2, s.qidx,
+                           (uint32_t)s.slot_words, s.qstage);
+        P3_HIP(hipGetLastError());
+        P3_HIP(hipMemcpyAsync(hp, s.qstage, (size_t)nq * s.slot_words * 4, hipMemcpyDeviceToHost, st));
+        P3_HIP(hipStreamSynchronize(st));
+    }
+
+    // ---- serialise (same layout as the test oracle's restatement) ----
+    std::vector<uint8_t>& pf = *proof;
+    pf.clear();
+    pf.reserve(64 + (size_t)nq * s.slot_words * 4 + 4096);
+    put_u32(pf, 0x42463350u); put_u32(pf, 1); put_u32(pf, log_n);
+    put_words(pf, root_t, 8); put_words(pf, root_q, 8);
+    put_u32(pf, 2); put_words(pf, opened[0].c, 4); put_words(pf, opened[1].c, 4);
+    put_u32(pf, 2); put_words(pf, opened[2].c, 4); put_words(pf, opened[3].c, 4);
+    put_u32(pf, 1); put_u32(pf, 4);
+    for (int k = 4; k < 8; k++) put_words(pf, opened[k].c, 4);
+    put_u32(pf, s.n_rounds); put_words(pf, froots.data(), froots.size());
+    put_u32(pf, nq);
+    for (uint32_t q = 0; q < nq; q++) {
+        const uint32_t* slot = hp + (size_t)q * s.slot_words;
+        put_u32(pf, 2);
+        put_u32(pf, 1); put_u32(pf, 2); put_words(pf, slot, 2); put_u32(pf, log_big); put_words(pf, slot + 2, (size_t)log_big * 8);
+        slot += 2 + log_big * 8;
+        put_u32(pf, 1); put_u32(pf, 4); put_words(pf, slot, 4); put_u32(pf, log_big); put_words(pf, slot + 4, (size_t)log_big * 8);
+        slot += 4 + log_big * 8;
+        put_u32(pf, s.n_rounds);
+        for (uint32_t r = 0; r < s.n_rounds; r++) {
+            uint32_t lh = log_big - 1 - r;
+            uint32_t idx = qidx[q] >> r;
+            put_words(pf, slot + 4 * ((idx ^ 1) & 1), 4);  // sibling_value
+            put_u32(pf, lh); put_words(pf, slot + 8, (size_t)lh * 8);
+            slot += 8 + lh * 8;
+        }
+    }
+    put_u32(pf, fpl);
+    for (uint32_t k = 0; k < fpl; k++) put_words(pf, fpoly[k].c, 4);
+    put_u32(pf, witness);
+    double t6 = now_ms();
+    s.times.trace_commit_ms += t1 - t0; s.times.quotient_commit_ms += t2 - t1; s.times.open_ms += t3 - t2;
+    s.times.fri_commit_ms += t4 - t3; s.times.grind_ms += t5 - t4; s.times.query_ms += t6 - t5; s.times.proofs += 1;
+    return OK;
+}
+
+const StageTimes& FibProver::times() const { return im->times; }
+void FibProver::reset_times() { im->times = StageTimes{}; }
+
+}  // namespace p3

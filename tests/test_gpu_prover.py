@@ -1,0 +1,88 @@
+"""GPU parity tests of the fib_air prover: proof bytes must equal the CPU oracle's byte for byte (every
+commitment, opened value, FRI layer root, witness and opening is in there), and the oracle's
+independently written verifier must accept them."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _fp(p3, oracle, *t):
+    return p3.FriParameters(*t), oracle.FriParams(*t)
+
+
+@pytest.mark.parametrize("log_n", [1, 2, 3, 5, 8, 10, 12, 14])
+def test_proof_bytes_equal_oracle(p3, oracle, log_n):
+    gfp, ofp = _fp(p3, oracle, 1, 0, 20, 8)
+    pr = p3.FibAirProver(log_n, params=gfp)
+    for a, b in [(0, 1), (7, 11)]:
+        proof = pr.prove(a, b)
+        ref = oracle.prove_fib_air(a, b, log_n, ofp)
+        assert len(proof) == len(ref)
+        if proof != ref:
+            w1, w2 = np.frombuffer(proof, np.uint32), np.frombuffer(ref, np.uint32)
+            first = int(np.nonzero(w1 != w2)[0][0])
+            pytest.fail("proof words differ first at %d of %d" % (first, len(w1)))
+        assert oracle.verify_fib_air(proof, a, b, oracle.fib_public_x(a, b, 1 << log_n), log_n, ofp) == 0
+    pr.close()
+
+
+@pytest.mark.parametrize("t", [(1, 0, 100, 16), (2, 0, 10, 4), (2, 2, 6, 5), (1, 3, 9, 0), (3, 1, 4, 10)])
+def test_fri_parameter_variants(p3, oracle, t):
+    gfp, ofp = _fp(p3, oracle, *t)
+    pr = p3.FibAirProver(9, params=gfp)
+    proof = pr.prove(3, 5)
+    assert proof == oracle.prove_fib_air(3, 5, 9, ofp)
+    assert oracle.verify_fib_air(proof, 3, 5, oracle.fib_public_x(3, 5, 512), 9, ofp) == 0
+
+
+def test_reference_instance(p3, oracle):
+    # the reference's own instance: n = 8, x = 21 (native/src/fib_air.rs:56-57)
+    gfp, ofp = _fp(p3, oracle, 1, 0, 10, 4)
+    proof = p3.FibAirProver(3, params=gfp).prove(0, 1)
+    assert oracle.verify_fib_air(proof, 0, 1, 21, 3, ofp) == 0
+    assert oracle.verify_fib_air(proof, 0, 1, 22, 3, ofp) != 0
+
+
+def test_headline_2_20_verifies_and_matches_commitments(p3, oracle):
+    """BASELINE cfg2 (2^20 rows, blowup 2, benchmark FRI parameters).  The full oracle proof takes ~20 s of
+    CPU; here: the oracle VERIFIER accepts the GPU proof, and the trace commitment inside the proof equals the
+    oracle's commitment of the same trace (bench.py's cpu_baseline leg compares the complete bytes)."""
+    gfp, ofp = _fp(p3, oracle, 1, 0, 100, 16)
+    pr = p3.FibAirProver(20, params=gfp)
+    proof = pr.prove(0, 1)
+    x = oracle.fib_public_x(0, 1, 1 << 20)
+    assert oracle.verify_fib_air(proof, 0, 1, x, 20, ofp) == 0
+    assert pr.prove(0, 1) == proof  # arena reuse is clean
+    words = np.frombuffer(proof, np.uint32)
+    lde = oracle.coset_lde_batch(oracle.generate_trace_rows(0, 1, 1 << 20), 1, p3.GENERATOR_MONTY, True)
+    root, _ = oracle.mmcs_commit([lde])
+    assert np.array_equal(words[3:11], root)
+    other = pr.prove(1, 2)
+    assert other != proof and oracle.verify_fib_air(other, 1, 2, oracle.fib_public_x(1, 2, 1 << 20), 20, ofp) == 0
+
+
+def test_concurrent_provers_on_threads(p3, oracle):
+    """One prover per host thread (per-thread context + own stream), as the batch bench runs them."""
+    gfp, ofp = _fp(p3, oracle, 1, 0, 16, 6)
+    out = {}
+
+    def work(i):
+        pr = p3.FibAirProver(11, params=gfp)
+        out[i] = [pr.prove(i, i + 1) for _ in range(2)]
+        pr.close()
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    for i in range(4):
+        ref = oracle.prove_fib_air(i, i + 1, 11, ofp)
+        assert out[i][0] == ref and out[i][1] == ref
+
+
+def test_bad_parameters(p3):
+    with pytest.raises(p3.P3HipError):
+        p3.FibAirProver(0)
+    with pytest.raises(p3.P3HipError):
+        p3.FibAirProver(27, params=p3.FriParameters(log_blowup=2))

@@ -1,54 +1,103 @@
-"""Benchmark job for bench.py: a batch of independent fib_air instances resident in HBM.
-Product-side only (no test oracle here); the CPU baseline leg lives in bench.py."""
+"""Benchmark job for bench.py: a batch of independent fib_air instances proved on one GPU.
+Product-side only (no test oracle here); the CPU baseline leg lives in bench.py.
+
+Independent proofs overlap on the device: each of `threads` host threads owns one prover (HBM arena +
+non-blocking stream + per-thread context) and proves its share of the step's instances; the transcript
+round trips of one proof hide behind the kernels of the others."""
 import ctypes as C
+import queue
+import threading
 
 import torch
 
 from . import _lib
+from .fib_air import FibAirProver, FriParameters, generate_trace_rows
 from .gpu_dft import GENERATOR_MONTY, BackendKind, GpuDft, _stream_ptr
-from .fib_air import generate_trace_rows
 from .mmcs import MerkleTreeMmcs
 
 
+class _Worker(threading.Thread):
+    def __init__(self, device, log_height, params):
+        super().__init__(daemon=True)
+        self.device, self.log_height, self.params = device, log_height, params
+        self.inbox, self.outbox = queue.Queue(), queue.Queue()
+        self.prover = None
+        self.start()
+
+    def run(self):
+        try:
+            torch.cuda.set_device(self.device)
+            self.prover = FibAirProver(self.log_height, params=self.params)
+            self.outbox.put(("ready", None))
+        except Exception as e:  # surfaced by the caller
+            self.outbox.put(("error", e))
+            return
+        while True:
+            job = self.inbox.get()
+            if job is None:
+                return
+            kind, arg = job
+            try:
+                if kind == "prove":
+                    self.outbox.put(("ok", [(i, self.prover.prove(a, a + 1)) for i, a in arg]))
+                elif kind == "stages":
+                    self.outbox.put(("ok", self.prover.stage_breakdown()))
+            except Exception as e:
+                self.outbox.put(("error", e))
+
+    def result(self):
+        status, val = self.outbox.get()
+        if status == "error":
+            raise val
+        return val
+
+
 class FibAirJob:
-    def __init__(self, p3, log_height, log_blowup, batch, first_instance=0):
+    def __init__(self, p3, log_height, log_blowup, batch, first_instance=0, threads=4):
         self.p3 = p3
+        self.device = torch.cuda.current_device()
         self.log_height, self.log_blowup, self.batch = log_height, log_blowup, batch
         self.first = first_instance
         self.n = 1 << log_height
         self.dft = GpuDft.with_backend(BackendKind.Hip)
         self.mmcs = MerkleTreeMmcs()
-        self.prover = getattr(p3, "FibAirProver", None)
-        if self.prover is not None:
-            self.prover = self.prover(log_height, log_blowup)
+        self.params = FriParameters(log_blowup=log_blowup)
+        self.threads = max(1, min(threads, batch))
+        self.workers = [_Worker(self.device, log_height, self.params) for _ in range(self.threads)]
+        for w in self.workers:
+            w.result()
         self.last = None
 
+    def close(self):
+        for w in self.workers:
+            w.inbox.put(None)
+
     def metric_name(self):
-        if self.prover is not None:
-            return "fib_air proofs/sec"
-        return "fib_air trace commitments/sec (coset LDE + Poseidon2 MMCS only; full prover not built yet)"
+        return "fib_air proofs/sec"
 
     def unit(self):
-        return "proofs/s" if self.prover is not None else "commitments/s"
+        return "proofs/s"
 
     def workload_name(self):
         return "fib_air 2^%d-row trace, BabyBear+Poseidon2, blowup %d (BASELINE configs[1])" % (
             self.log_height, 1 << self.log_blowup)
 
     def step(self):
-        outs = []
-        for i in range(self.batch):
-            a = self.first + i
-            if self.prover is not None:
-                outs.append(self.prover.prove(a, a + 1))
-            else:
-                trace = generate_trace_rows(a, a + 1, self.n)
-                lde = self.dft.coset_lde_batch(trace, self.log_blowup, GENERATOR_MONTY, bit_reversed_out=True)
-                root, tree = self.mmcs.commit([lde])
-                outs.append(root)
-                tree.free()
-        self.last = outs
-        return outs
+        """Proves `batch` independent instances (a, b) = (first+i, first+i+1); returns the proof bytes."""
+        for t, w in enumerate(self.workers):
+            w.inbox.put(("prove", [(i, self.first + i) for i in range(t, self.batch, self.threads)]))
+        res = [None] * self.batch
+        for w in self.workers:
+            for i, pf in w.result():
+                res[i] = pf
+        self.last = res
+        return res
+
+    def prove_one(self, a, b):
+        w = self.workers[0]
+        w.inbox.put(("prove", [(0, a)]))
+        assert b == a + 1
+        return w.result()[0][1]
 
     def _time(self, fn, reps):
         fn()
@@ -62,7 +111,8 @@ class FibAirJob:
         return sum(s.elapsed_time(e) for s, e in evs) / reps  # ms
 
     def lde_roofline(self, reps=20):
-        """coset LDE of one 2^h x 2 trace: algorithmic bytes = 4*h*w*(1+blowup)."""
+        """coset LDE of one 2^h x 2 trace: algorithmic bytes = 4*h*w*(1+blowup).
+        HIP events on the stream the kernels are launched on (torch's current stream)."""
         trace = generate_trace_rows(0, 1, self.n)
         out = torch.empty((self.n << self.log_blowup, 2), dtype=torch.int32, device="cuda")
         L = _lib.lib()
@@ -73,7 +123,7 @@ class FibAirJob:
         ms = self._time(run, reps)
         nbytes = 4 * self.n * 2 * (1 + (1 << self.log_blowup))
         res = {"bytes": nbytes, "avg_us": ms * 1e3, "gbps": nbytes / (ms * 1e-3) / 1e9}
-        # same unit over a wide batch (64 traces side by side = 2^h x 128): out of L2/Infinity-cache regime
+        # same unit over a wide batch (64 traces side by side = 2^h x 128): out of the L2/Infinity-Cache regime
         wide = torch.randint(0, 0x78000001, (self.n, 128), dtype=torch.int32, device="cuda")
         wout = torch.empty((self.n << self.log_blowup, 128), dtype=torch.int32, device="cuda")
 
@@ -95,6 +145,7 @@ class FibAirJob:
             t.free()
         t_commit = self._time(commit, 5)
         out = {"trace_gen": t_trace, "trace_lde": t_lde, "trace_commit": t_commit}
-        if self.prover is not None and hasattr(self.prover, "stage_breakdown"):
-            out.update(self.prover.stage_breakdown())
+        w = self.workers[0]
+        w.inbox.put(("stages", None))
+        out.update(w.result())  # single-proof latency split, host wall clock
         return out

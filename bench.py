@@ -18,6 +18,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# concurrent provers each own a stream; give them distinct hardware queues (ROCm default is 4)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 
@@ -45,12 +47,12 @@ def cpu_baseline(log_height, log_blowup, job):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-height", type=int, default=20)
     ap.add_argument("--log-blowup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=8, help="independent proofs per rank per step")
-    ap.add_argument("--threads", type=int, default=4, help="concurrent provers (host threads/streams) per rank")
+    ap.add_argument("--batch", type=int, default=32, help="independent proofs per rank per step")
+    ap.add_argument("--threads", type=int, default=8, help="concurrent provers (host threads/streams) per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

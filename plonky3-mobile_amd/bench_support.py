@@ -5,7 +5,9 @@ Independent proofs overlap on the device: each of `threads` host threads owns on
 non-blocking stream + per-thread context) and proves its share of the step's instances; the transcript
 round trips of one proof hide behind the kernels of the others."""
 import ctypes as C
+import os
 import queue
+import time
 import threading
 
 import torch
@@ -17,8 +19,9 @@ from .mmcs import MerkleTreeMmcs
 
 
 class _Worker(threading.Thread):
-    def __init__(self, device, log_height, params):
+    def __init__(self, device, log_height, params, stagger_s=0.0):
         super().__init__(daemon=True)
+        self.stagger_s = stagger_s
         self.device, self.log_height, self.params = device, log_height, params
         self.inbox, self.outbox = queue.Queue(), queue.Queue()
         self.prover = None
@@ -39,7 +42,19 @@ class _Worker(threading.Thread):
             kind, arg = job
             try:
                 if kind == "prove":
-                    self.outbox.put(("ok", [(i, self.prover.prove(a, a + 1)) for i, a in arg]))
+                    # work-stealing over the step's shared queue of (slot, a); the first step is staggered so the
+                    # provers do not run their small-kernel phases (tree tops, FRI tail) in lockstep
+                    if self.stagger_s:
+                        time.sleep(self.stagger_s)
+                        self.stagger_s = 0.0
+                    done = []
+                    while True:
+                        try:
+                            i, a = arg.get_nowait()
+                        except queue.Empty:
+                            break
+                        done.append((i, self.prover.prove(a, a + 1)))
+                    self.outbox.put(("ok", done))
                 elif kind == "stages":
                     self.outbox.put(("ok", self.prover.stage_breakdown()))
             except Exception as e:
@@ -63,7 +78,8 @@ class FibAirJob:
         self.mmcs = MerkleTreeMmcs()
         self.params = FriParameters(log_blowup=log_blowup)
         self.threads = max(1, min(threads, batch))
-        self.workers = [_Worker(self.device, log_height, self.params) for _ in range(self.threads)]
+        stag = float(os.environ.get("P3HIP_BENCH_STAGGER_MS", "1.0")) * 1e-3
+        self.workers = [_Worker(self.device, log_height, self.params, stag * t) for t in range(self.threads)]
         for w in self.workers:
             w.result()
         self.last = None
@@ -84,8 +100,11 @@ class FibAirJob:
 
     def step(self):
         """Proves `batch` independent instances (a, b) = (first+i, first+i+1); returns the proof bytes."""
-        for t, w in enumerate(self.workers):
-            w.inbox.put(("prove", [(i, self.first + i) for i in range(t, self.batch, self.threads)]))
+        jobs = queue.Queue()
+        for i in range(self.batch):
+            jobs.put((i, self.first + i))
+        for w in self.workers:
+            w.inbox.put(("prove", jobs))
         res = [None] * self.batch
         for w in self.workers:
             for i, pf in w.result():
@@ -95,7 +114,9 @@ class FibAirJob:
 
     def prove_one(self, a, b):
         w = self.workers[0]
-        w.inbox.put(("prove", [(0, a)]))
+        jobs = queue.Queue()
+        jobs.put((0, a))
+        w.inbox.put(("prove", jobs))
         assert b == a + 1
         return w.result()[0][1]
 

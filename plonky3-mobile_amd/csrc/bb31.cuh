@@ -47,7 +47,20 @@ BB_HD uint32_t monty_reduce(uint64_t x) {
     uint32_t r = hi - u;
     return umin32(r, r + P);
 }
-BB_HD uint32_t mul(uint32_t a, uint32_t b) { return monty_reduce((uint64_t)a * b); }
+// Montgomery product.  lo/hi are taken with separate v_mul_lo_u32 / v_mul_hi_u32: hipcc otherwise fuses the
+// 64-bit product into v_mad_u64_u32, which issues ~3x slower than the pair on gfx950
+// (profiles/r01_microbench_int_valu.txt).
+BB_HD uint32_t mul(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t lo = a * b, hi = __umulhi(a, b);
+    uint32_t t = lo * MU;
+    uint32_t u = __umulhi(t, P);
+    uint32_t r = hi - u;
+    return umin32(r, r + P);
+#else
+    return monty_reduce((uint64_t)a * b);
+#endif
+}
 BB_HD uint32_t sqr(uint32_t a) { return mul(a, a); }
 BB_HD uint32_t to_monty(uint32_t canon) { return mul(canon, R2); }
 BB_HD uint32_t from_monty(uint32_t m) { return monty_reduce((uint64_t)m); }
@@ -74,6 +87,28 @@ BB_HD uint32_t two_adic_generator(uint32_t bits) {
 BB_HD uint32_t pow7(uint32_t x) {
     uint32_t x2 = sqr(x), x3 = mul(x2, x), x4 = sqr(x2);
     return mul(x3, x4);
+}
+
+// Signed Montgomery product (Seiler): inputs in (-P, P) as int32, output in (-P, P), FIVE integer ops and
+// no correction: r = hi(a*b) - hi(t*P), t = lo(a*b) * P^-1 (signed).  |r| < (P^2 + 2^31 P)/2^32 < P.
+BB_HD int32_t smul(int32_t a, int32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int32_t lo = (int32_t)((uint32_t)a * (uint32_t)b), hi = __mulhi(a, b);
+    int32_t t = (int32_t)((uint32_t)lo * MU);
+    return hi - __mulhi(t, (int32_t)P);
+#else
+    int64_t x = (int64_t)a * b;
+    int32_t t = (int32_t)((uint32_t)x * MU);
+    return (int32_t)((x - (int64_t)t * (int64_t)P) >> 32);
+#endif
+}
+// (s + rc)^7 for s, rc in [0, P): the sum enters the chain as s + (rc - P) in [-P, P) (one add), the four
+// products stay signed, one final correction brings the result back to [0, P).
+BB_HD uint32_t sbox7_add(uint32_t s, uint32_t rc) {
+    int32_t x = (int32_t)(s + (rc - P));
+    int32_t x2 = smul(x, x), x3 = smul(x2, x), x4 = smul(x2, x2);
+    uint32_t r = (uint32_t)smul(x3, x4);
+    return umin32(r, r + P);
 }
 
 // ---- quartic extension F[x]/(x^4 - 11) (Challenge = BinomialExtensionField<BabyBear,4>,

@@ -11,6 +11,7 @@ struct Tree {
     std::vector<size_t> heights, widths;
     std::vector<void*> owned;           // device copies made by the host-pointer commit
     uint32_t* layers = nullptr;         // all digest layers, leaf layer first, 8 words per digest
+    bool root_copied = false;           // the top kernel also wrote the root to the caller's host-mapped buffer
     bool owns_layers = true;            // false: caller-provided arena (prover), nothing to free
     std::vector<size_t> layer_off, layer_len;  // offsets in words / lengths in digests
     uint32_t log_max_height = 0;
@@ -21,7 +22,7 @@ struct Tree {
 
 // ext_layers: optional caller-owned storage of (2*max_height - 1) * 8 words for the digest layers.
 int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t* heights, const size_t* widths,
-                size_t n_mats, Tree** out, uint32_t* ext_layers = nullptr);
+                size_t n_mats, Tree** out, uint32_t* ext_layers = nullptr, uint32_t* root_copy = nullptr);
 inline size_t mmcs_layer_words(uint64_t max_height) { return (size_t)(2 * max_height - 1) * 8; }
 int mmcs_root(hipStream_t stream, const Tree& t, uint32_t root_out[8]);
 int mmcs_open(hipStream_t stream, const Tree& t, uint64_t index, uint32_t* rows_out, uint32_t* path_out);

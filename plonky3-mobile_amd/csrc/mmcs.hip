@@ -10,6 +10,7 @@
 #include "common.h"
 #include "mmcs.h"
 #include "poseidon2.cuh"
+#include "poseidon2_coop.cuh"
 
 namespace p3 {
 
@@ -119,6 +120,70 @@ __global__ void __launch_bounds__(256) tree_top_kernel(uint32_t* layer0, uint32_
     }
 }
 
+
+// ---- lane-cooperative kernels for small layers (16 lanes per permutation, poseidon2_coop.cuh) ----
+// next[i] = compress(prev[2i], prev[2i+1]); one 16-lane row per output digest.
+__global__ void __launch_bounds__(256) compress_coop_kernel(const uint32_t* prev, uint32_t* next, uint32_t n_out) {
+    const uint32_t lane16 = threadIdx.x & 15;
+    const p2c::LaneConst lc = p2c::lane_constants(lane16);
+    uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    bool act = i < n_out;
+    uint32_t v = act ? prev[(size_t)i * 16 + lane16] : 0u;
+    v = p2c::permute(v, lc);
+    if (act && lane16 < 8) next[(size_t)i * 8 + lane16] = v;
+}
+// leaf digests of ONE matrix (any width): row r absorbed 8 words at a time by lanes 0..7 of its row of lanes.
+__global__ void __launch_bounds__(256) leaf_coop_kernel(const uint32_t* mat, uint32_t width, uint32_t n_rows, uint32_t* digests) {
+    const uint32_t lane16 = threadIdx.x & 15;
+    const p2c::LaneConst lc = p2c::lane_constants(lane16);
+    uint32_t r = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    bool act = r < n_rows;
+    uint32_t v = 0;
+    for (uint32_t k = 0; k < width; k += 8) {
+        if (act && lane16 < 8 && k + lane16 < width) v = mat[(size_t)r * width + k + lane16];
+        v = p2c::permute(v, lc);
+    }
+    if (act && lane16 < 8) digests[(size_t)r * 8 + lane16] = v;
+}
+// All remaining (injection-free) levels of a tree whose current layer has n0 <= 1024 digests, one workgroup
+// of 1024 lanes = 64 cooperative rows; the current layer lives in LDS, every layer is also written to HBM.
+__global__ void __launch_bounds__(1024) tree_top_coop_kernel(uint32_t* layer0, uint32_t n0, uint32_t* root_copy) {
+    __shared__ uint32_t lds[1024 * 8];
+    const uint32_t tid = threadIdx.x, lane16 = tid & 15, grp = tid >> 4;
+    const p2c::LaneConst lc = p2c::lane_constants(lane16);
+    for (uint32_t i = tid; i < n0 * 8; i += blockDim.x) lds[i] = layer0[i];
+    __syncthreads();
+    uint32_t* out = layer0 + (size_t)n0 * 8;
+    for (uint32_t n = n0; n > 1; n >>= 1) {
+        const uint32_t half = n >> 1;
+        // batches of 64 permutations; results are held until every batch of the level has read its inputs
+        uint32_t res[8];
+        const uint32_t nb = (half + 63) >> 6;  // <= 8
+#pragma unroll
+        for (uint32_t bi = 0; bi < 8; bi++) {
+            if (bi < nb) {
+                uint32_t i = bi * 64 + grp;
+                uint32_t v = i < half ? lds[i * 16 + lane16] : 0u;
+                res[bi] = p2c::permute(v, lc);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t bi = 0; bi < 8; bi++) {
+            if (bi < nb) {
+                uint32_t i = bi * 64 + grp;
+                if (i < half && lane16 < 8) {
+                    lds[i * 8 + lane16] = res[bi];
+                    out[(size_t)i * 8 + lane16] = res[bi];
+                    if (half == 1 && root_copy) root_copy[lane16] = res[bi];  // host-mapped: no D2H copy needed
+                }
+            }
+        }
+        __syncthreads();
+        out += (size_t)half * 8;
+    }
+}
+
 __global__ void poseidon2_permute_kernel(uint32_t* states, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -182,8 +247,13 @@ Tree::~Tree() {
     for (void* p : owned) (void)hipFree(p);
 }
 
+static uint32_t top_digests() {
+    static uint32_t v = [] { const char* e = getenv("P3HIP_TREE_TOP"); uint32_t x = e ? (uint32_t)atoi(e) : 64u; return x < 2 ? 2u : (x > 1024 ? 1024u : x); }();
+    return v;
+}
+
 int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t* heights, const size_t* widths,
-                size_t n_mats, Tree** out, uint32_t* ext_layers) {
+                size_t n_mats, Tree** out, uint32_t* ext_layers, uint32_t* root_copy) {
     if (!n_mats || !d_mats || !heights || !widths || !out) return fail(ERR_BAD_ARG, "mmcs_commit: null/empty argument");
     if (n_mats > 64) return fail(ERR_BAD_ARG, "mmcs_commit: at most 64 matrices per commitment");
     uint64_t maxh = 0;
@@ -215,27 +285,39 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
         off += len * 8;
         if (len == 1) break;
     }
-    // leaf layer
+    // Layers with fewer than COOP_MAX permutations cannot fill the chip with one state per lane: they run the
+    // 16-lanes-per-state kernels (latency ~6x lower); the last <= 1024 digests finish inside one workgroup.
+    const uint64_t COOP_MAX = 1u << 15;
     {
         RowSet rs = make_rowset(*t, maxh);
-        hipLaunchKernelGGL(leaf_hash_kernel, dim3((uint32_t)((maxh + 255) / 256)), dim3(256), 0, stream, rs, maxh, t->layers);
+        if (rs.count == 1 && maxh < COOP_MAX && maxh * 16 <= 0x7fffffffull) {
+            hipLaunchKernelGGL(leaf_coop_kernel, dim3((uint32_t)((maxh * 16 + 255) / 256)), dim3(256), 0, stream, rs.ptr[0],
+                               rs.width[0], (uint32_t)maxh, t->layers);
+        } else {
+            hipLaunchKernelGGL(leaf_hash_kernel, dim3((uint32_t)((maxh + 255) / 256)), dim3(256), 0, stream, rs, maxh, t->layers);
+        }
         P3_HIP(hipGetLastError());
     }
     for (size_t l = 1; l < t->layer_len.size(); l++) {
         uint64_t len = t->layer_len[l];
         RowSet rs = make_rowset(*t, len);
         bool inject = rs.count > 0;
-        // remaining levels injection-free and small: finish inside one workgroup
         bool more_inject = false;
         for (size_t i = 0; i < n_mats; i++) more_inject |= heights[i] <= len;
-        if (!more_inject && t->layer_len[l - 1] <= 512) {
+        if (!more_inject && t->layer_len[l - 1] <= top_digests()) {
             uint32_t n0 = (uint32_t)t->layer_len[l - 1];
-            hipLaunchKernelGGL(tree_top_kernel, dim3(1), dim3(256), (size_t)n0 * 32, stream, t->layers + t->layer_off[l - 1], n0);
+            hipLaunchKernelGGL(tree_top_coop_kernel, dim3(1), dim3(1024), 0, stream, t->layers + t->layer_off[l - 1], n0, root_copy);
+            t->root_copied = root_copy != nullptr;
             P3_HIP(hipGetLastError());
             break;
         }
-        hipLaunchKernelGGL(compress_layer_kernel, dim3((uint32_t)((len + 255) / 256)), dim3(256), 0, stream,
-                           t->layers + t->layer_off[l - 1], t->layers + t->layer_off[l], len, rs, inject ? 1u : 0u);
+        if (!inject && len < COOP_MAX) {
+            hipLaunchKernelGGL(compress_coop_kernel, dim3((uint32_t)((len * 16 + 255) / 256)), dim3(256), 0, stream,
+                               t->layers + t->layer_off[l - 1], t->layers + t->layer_off[l], (uint32_t)len);
+        } else {
+            hipLaunchKernelGGL(compress_layer_kernel, dim3((uint32_t)((len + 255) / 256)), dim3(256), 0, stream,
+                               t->layers + t->layer_off[l - 1], t->layers + t->layer_off[l], len, rs, inject ? 1u : 0u);
+        }
         P3_HIP(hipGetLastError());
     }
     *out = t.release();

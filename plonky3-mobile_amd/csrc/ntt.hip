@@ -2,7 +2,7 @@
 //
 // Replaces the reference's per-stage Vulkan dispatch loop (native/src/backend_vulkan.rs:1182-1294,
 // kernels native/shaders/fft_stage.wgsl:75-136 and fft_stage_fused.wgsl:67-139), which costs log2(H)
-// full HBM round trips.  Here a transform of 2^n rows is cut into 1-3 PASSES of b <= 11 stages; a
+// full HBM round trips.  Here a transform of 2^n rows is cut into 1-3 PASSES of b <= 9 stages (up to 11 supported); a
 // workgroup stages a [2^b points] x [RUN independent words] tile in LDS (row stride RUN+1, so both
 // the row-wise and the column-wise copies are bank-conflict free), runs the b stages as register
 // radix-2^r rounds (r <= 5, one LDS round trip per round), and writes the tile back once.  Passes
@@ -178,6 +178,78 @@ __device__ __forceinline__ bool decode_side(const PassArgs& a, uint32_t kind, ui
     return true;
 }
 
+// Row-wise sides (runs of RUN contiguous words per tile row): lane x is fixed per thread and the tile row
+// advances linearly with the unrolled slot index j, so all address arithmetic is hoisted and the R loads of
+// a lane are issued back to back (one latency per pass instead of R).
+struct RowSide {
+    uint32_t valid, lo;
+    uint64_t base_word, base_row;  // word / row at pt = 0 (INPLACE, GROUP*) or the h part (STRIDED)
+    uint32_t c;
+};
+template <uint32_t RUN>
+__device__ __forceinline__ bool side_is_rowwise(const PassArgs& a, uint32_t kind) {
+    return kind == SIDE_INPLACE || kind == SIDE_STRIDED || a.W >= RUN;
+}
+template <uint32_t RUN>
+__device__ __forceinline__ RowSide rowside_init(const PassArgs& a, uint32_t kind, uint32_t x, uint32_t hi, uint32_t h0,
+                                                uint32_t c0, uint64_t f0) {
+    RowSide r{};
+    const uint32_t b = a.b;
+    if (kind == SIDE_INPLACE) {
+        uint64_t f = f0 + x;
+        r.valid = f < ((uint64_t)a.W << a.s0);
+        r.lo = a.wshift != 0xffffffffu ? (uint32_t)(f >> a.wshift) : (uint32_t)(f / a.W);
+        r.base_row = ((uint64_t)hi << (a.s0 + b)) + r.lo;
+        r.base_word = ((uint64_t)hi << (a.s0 + b)) * a.W + f;
+        return r;
+    }
+    uint32_t t = 0, c;
+    if (a.W < RUN) {
+        if (a.wshift != 0xffffffffu) { t = x >> a.wshift; c = x & (a.W - 1); }
+        else { t = x / a.W; c = x - t * a.W; }
+        r.valid = t < a.G;
+    } else {
+        c = c0 + x;
+        r.valid = c < a.W;
+    }
+    const uint32_t gbits = a.n - b;
+    uint64_t h = (uint64_t)h0 + t;
+    if (h >= (1ull << gbits)) r.valid = 0;
+    r.c = c;
+    if (kind == SIDE_STRIDED) r.base_row = h;
+    else r.base_row = (kind == SIDE_GROUP_REV ? (uint64_t)rev_bits((uint32_t)h, gbits) : h) << b;
+    return r;
+}
+__device__ __forceinline__ void rowside_addr(const PassArgs& a, uint32_t kind, const RowSide& r, uint32_t pt,
+                                             uint64_t& word, uint64_t& row) {
+    if (kind == SIDE_INPLACE) {
+        row = r.base_row + ((uint64_t)pt << a.s0);
+        word = r.base_word + ((uint64_t)pt << a.s0) * a.W;
+    } else if (kind == SIDE_STRIDED) {
+        row = ((uint64_t)rev_bits(pt, a.b) << (a.n - a.b)) + r.base_row;
+        word = row * a.W + r.c;
+    } else {
+        row = r.base_row + pt;
+        word = row * a.W + r.c;
+    }
+}
+
+// Column-wise sides (contiguous groups of a narrow power-of-two-width matrix): slot idx -> c fastest, then
+// tile row pt, then group t, all by shifts; lanes walk contiguous global words of one group.
+__device__ __forceinline__ bool colside_addr(const PassArgs& a, uint32_t kind, uint32_t idx, uint32_t h0, uint32_t& pt,
+                                             uint32_t& x, uint64_t& word, uint64_t& row) {
+    const uint32_t b = a.b, gbits = a.n - b;
+    uint32_t c = idx & (a.W - 1), q = idx >> a.wshift;
+    pt = q & ((1u << b) - 1u);
+    uint32_t t = q >> b;
+    x = (t << a.wshift) + c;
+    uint64_t h = (uint64_t)h0 + t;
+    if (t >= a.G || h >= (1ull << gbits)) return false;
+    row = ((kind == SIDE_GROUP_REV ? (uint64_t)rev_bits((uint32_t)h, gbits) : h) << b) + pt;
+    word = (row << a.wshift) + c;
+    return true;
+}
+
 template <int LOG_RUN, int LOG_R>
 __global__ void __launch_bounds__(1024) ntt_pass_kernel(PassArgs a) {
     constexpr uint32_t RUN = 1u << LOG_RUN, STRIDE = RUN + 1;
@@ -201,30 +273,83 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(PassArgs a) {
     }
 
     const uint32_t total = npts * RUN;
+    constexpr uint32_t R = 1u << LOG_R;
+    const bool full = nth == (total >> LOG_R);  // one slot per (thread, j): the unrolled fast paths apply
+    const uint32_t xr = tid & (RUN - 1), pt0 = tid >> LOG_RUN, dpt = nth >> LOG_RUN;
     // ---- load ----
-    for (uint32_t idx = tid; idx < total; idx += nth) {
-        uint32_t pt, x, lo;
-        uint64_t word, row;
-        bool ok = decode_side<RUN>(a, a.load_kind, idx, hi, h0, c0, f0, pt, x, word, row, lo);
-        uint32_t v = 0;
-        if (ok) {
-            if (row < a.src_rows) {
-                v = a.src[word];
-                if (a.has_sc) v = bb::mul(v, two_level(a.sc_lo, a.sc_hi, a.sc_T, row));
+    if (full && side_is_rowwise<RUN>(a, a.load_kind)) {
+        const RowSide rs = rowside_init<RUN>(a, a.load_kind, xr, hi, h0, c0, f0);
+        uint32_t v[R];
+#pragma unroll
+        for (uint32_t j = 0; j < R; j++) {
+            uint64_t word, row;
+            rowside_addr(a, a.load_kind, rs, pt0 + j * dpt, word, row);
+            v[j] = (rs.valid && row < a.src_rows) ? a.src[word] : 0u;
+        }
+        if (a.has_sc) {
+#pragma unroll
+            for (uint32_t j = 0; j < R; j++) {
+                uint64_t word, row;
+                rowside_addr(a, a.load_kind, rs, pt0 + j * dpt, word, row);
+                if (rs.valid && row < a.src_rows) v[j] = bb::mul(v[j], two_level(a.sc_lo, a.sc_hi, a.sc_T, row));
             }
-            if (a.has_tw && !a.dif)
-                v = bb::mul(v, two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)rev_bits(pt, b) * lo));
-            tile[pt * STRIDE + x] = v;
-        } else if (a.load_kind == SIDE_INPLACE || !(a.W < RUN && a.load_kind != SIDE_STRIDED)) {
-            // row-wise decode: (pt, x) are valid tile coordinates even for padding slots
-            tile[pt * STRIDE + x] = 0;
+        }
+        if (a.has_tw && !a.dif) {
+#pragma unroll
+            for (uint32_t j = 0; j < R; j++)
+                v[j] = bb::mul(v[j], two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)rev_bits(pt0 + j * dpt, b) * rs.lo));
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < R; j++) tile[(pt0 + j * dpt) * STRIDE + xr] = v[j];
+    } else if (full && a.wshift != 0xffffffffu) {
+        // narrow power-of-two width, contiguous-group side (s0 == 0: no twiddle on this side)
+        uint32_t v[R];
+#pragma unroll
+        for (uint32_t j = 0; j < R; j++) {
+            uint32_t pt, x;
+            uint64_t word, row;
+            bool ok = colside_addr(a, a.load_kind, tid + j * nth, h0, pt, x, word, row);
+            v[j] = (ok && row < a.src_rows) ? a.src[word] : 0u;
+        }
+        if (a.has_sc) {
+#pragma unroll
+            for (uint32_t j = 0; j < R; j++) {
+                uint32_t pt, x;
+                uint64_t word, row;
+                if (colside_addr(a, a.load_kind, tid + j * nth, h0, pt, x, word, row) && row < a.src_rows)
+                    v[j] = bb::mul(v[j], two_level(a.sc_lo, a.sc_hi, a.sc_T, row));
+            }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < R; j++) {
+            uint32_t pt, x;
+            uint64_t word, row;
+            if (colside_addr(a, a.load_kind, tid + j * nth, h0, pt, x, word, row)) tile[pt * STRIDE + x] = v[j];
+        }
+    } else {
+        for (uint32_t idx = tid; idx < total; idx += nth) {
+            uint32_t pt, x, lo;
+            uint64_t word, row;
+            bool ok = decode_side<RUN>(a, a.load_kind, idx, hi, h0, c0, f0, pt, x, word, row, lo);
+            uint32_t v = 0;
+            if (ok) {
+                if (row < a.src_rows) {
+                    v = a.src[word];
+                    if (a.has_sc) v = bb::mul(v, two_level(a.sc_lo, a.sc_hi, a.sc_T, row));
+                }
+                if (a.has_tw && !a.dif)
+                    v = bb::mul(v, two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)rev_bits(pt, b) * lo));
+                tile[pt * STRIDE + x] = v;
+            } else if (a.load_kind == SIDE_INPLACE || !(a.W < RUN && a.load_kind != SIDE_STRIDED)) {
+                tile[pt * STRIDE + x] = 0;  // row-wise decode: (pt, x) are valid tile coordinates even for padding
+            }
         }
     }
     __syncthreads();
 
     // ---- b stages as register-radix rounds ----
     const uint32_t nwork = total >> LOG_R;
-    const uint32_t x = tid & (RUN - 1), g = tid >> LOG_RUN;
+    const uint32_t x = xr, g = pt0;
     if (!a.dif) {
         for (uint32_t k0 = 0; k0 < b;) {
             uint32_t rr = (b - k0) < (uint32_t)LOG_R ? (b - k0) : (uint32_t)LOG_R;
@@ -242,6 +367,50 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(PassArgs a) {
     }
 
     // ---- store ----
+    if (full && side_is_rowwise<RUN>(a, a.store_kind)) {
+        const RowSide rs = rowside_init<RUN>(a, a.store_kind, xr, hi, h0, c0, f0);
+        if (!rs.valid) return;
+        uint32_t v[R];
+#pragma unroll
+        for (uint32_t j = 0; j < R; j++) v[j] = tile[(pt0 + j * dpt) * STRIDE + xr];
+        if (a.has_tw && a.dif) {
+#pragma unroll
+            for (uint32_t j = 0; j < R; j++)
+                v[j] = bb::mul(v[j], two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)rev_bits(pt0 + j * dpt, b) * rs.lo));
+        }
+        if (a.has_us) {
+#pragma unroll
+            for (uint32_t j = 0; j < R; j++) v[j] = bb::mul(v[j], a.uscale);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < R; j++) {
+            uint64_t word, row;
+            rowside_addr(a, a.store_kind, rs, pt0 + j * dpt, word, row);
+            a.dst[word] = v[j];
+        }
+        return;
+    }
+    if (full && a.wshift != 0xffffffffu) {
+        uint32_t v[R];
+#pragma unroll
+        for (uint32_t j = 0; j < R; j++) {
+            uint32_t pt, x;
+            uint64_t word, row;
+            bool ok = colside_addr(a, a.store_kind, tid + j * nth, h0, pt, x, word, row);
+            v[j] = ok ? tile[pt * STRIDE + x] : 0u;
+        }
+        if (a.has_us) {
+#pragma unroll
+            for (uint32_t j = 0; j < R; j++) v[j] = bb::mul(v[j], a.uscale);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < R; j++) {
+            uint32_t pt, x;
+            uint64_t word, row;
+            if (colside_addr(a, a.store_kind, tid + j * nth, h0, pt, x, word, row)) a.dst[word] = v[j];
+        }
+        return;
+    }
     for (uint32_t idx = tid; idx < total; idx += nth) {
         uint32_t pt, xx, lo;
         uint64_t word, row;
@@ -280,13 +449,22 @@ int bit_reverse_rows(hipStream_t stream, const uint32_t* src, uint32_t* dst, uin
 // ---------------------------------------------------------------------------------------------
 namespace {
 
-constexpr uint32_t B_MAX = 11;
+// Largest tile (log2 points per pass).  Tunable for experiments: P3HIP_NTT_BMAX=7..11.
+uint32_t b_max() {
+    static uint32_t v = [] {
+        const char* e = getenv("P3HIP_NTT_BMAX");
+        uint32_t x = e ? (uint32_t)atoi(e) : 9u;  // measured best on MI355X: 2^20/2^21 -> three 7-stage passes
+        return x < 4 ? 4u : (x > 11 ? 11u : x);
+    }();
+    return v;
+}
 
 // Digits, lowest position digit first.
 std::vector<uint32_t> split_digits(uint32_t n) {
     std::vector<uint32_t> d;
     if (n == 0) return d;
-    uint32_t passes = n <= B_MAX ? 1 : (n <= 2 * B_MAX ? 2 : 3);
+    const uint32_t B_MAX = b_max();
+    uint32_t passes = (n + B_MAX - 1) / B_MAX;
     uint32_t rem = n;
     for (uint32_t i = 0; i < passes; i++) {
         uint32_t b = (rem + (passes - i) - 1) / (passes - i);

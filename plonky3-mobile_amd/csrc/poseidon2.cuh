@@ -19,12 +19,15 @@ BB_HD uint32_t div2k(uint32_t x) {
     return ((x + m) >> K) + ((m * 15u) << (27 - K));
 }
 
+// [2 3 1 1; 1 2 3 1; 1 1 2 3; 3 1 1 2] with 7 additions and 2 doublings
 BB_HD void mat4(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) {
-    uint32_t s = bb::add(bb::add(a, b), bb::add(c, d));
-    uint32_t na = bb::add(bb::add(s, a), bb::dbl(b));
-    uint32_t nb = bb::add(bb::add(s, b), bb::dbl(c));
-    uint32_t nc = bb::add(bb::add(s, c), bb::dbl(d));
-    uint32_t nd = bb::add(bb::add(s, d), bb::dbl(a));
+    uint32_t t01 = bb::add(a, b), t23 = bb::add(c, d);
+    uint32_t t0123 = bb::add(t01, t23);
+    uint32_t t01123 = bb::add(t0123, b), t01233 = bb::add(t0123, d);
+    uint32_t nd = bb::add(t01233, bb::dbl(a));  // 3a + b + c + 2d
+    uint32_t nb = bb::add(t01123, bb::dbl(c));  // a + 2b + 3c + d
+    uint32_t na = bb::add(t01123, t01);         // 2a + 3b + c + d
+    uint32_t nc = bb::add(t01233, t23);         // a + b + 2c + 3d
     a = na; b = nb; c = nc; d = nd;
 }
 
@@ -63,23 +66,51 @@ BB_HD void internal_linear(uint32_t (&s)[16]) {
     s[15] = bb::sub(tot, div2k<27>(s[15]));           // -2^-27
 }
 
+// Round constants for device code live in __constant__ memory and the round loops stay ROLLED: fully
+// unrolled, the permutation is ~55 KB of straight-line code and every wave streams it through the 64 KB
+// instruction cache at its own position — the kernel then runs at instruction-fetch speed, not VALU speed
+// (measured: 13% fewer VALU ops changed nothing while unrolled).  Rolled, the loop bodies are ~6 KB.
+struct RoundConstants {
+    uint32_t ext[8][16];
+    uint32_t in[13];
+};
+constexpr RoundConstants make_round_constants() {
+    RoundConstants rc{};
+    for (int r = 0; r < 4; r++)
+        for (int i = 0; i < 16; i++) {
+            rc.ext[r][i] = P3_RC16_EXT_INIT_MONTY[r][i];
+            rc.ext[4 + r][i] = P3_RC16_EXT_FINAL_MONTY[r][i];
+        }
+    for (int r = 0; r < 13; r++) rc.in[r] = P3_RC16_INTERNAL_MONTY[r];
+    return rc;
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __constant__ RoundConstants d_rc = make_round_constants();
+#define P2_RC d_rc
+#define P2_ROLLED _Pragma("clang loop unroll(disable)")
+#else
+static constexpr RoundConstants h_rc = make_round_constants();
+#define P2_RC h_rc
+#define P2_ROLLED
+#endif
+
 BB_HD void permute(uint32_t (&s)[16]) {
     external_linear(s);
-#pragma unroll
+    P2_ROLLED
     for (int r = 0; r < 4; r++) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) s[i] = bb::pow7(bb::add(s[i], P3_RC16_EXT_INIT_MONTY[r][i]));
+        for (int i = 0; i < 16; i++) s[i] = bb::sbox7_add(s[i], P2_RC.ext[r][i]);
         external_linear(s);
     }
-#pragma unroll
+    P2_ROLLED
     for (int r = 0; r < 13; r++) {
-        s[0] = bb::pow7(bb::add(s[0], P3_RC16_INTERNAL_MONTY[r]));
+        s[0] = bb::sbox7_add(s[0], P2_RC.in[r]);
         internal_linear(s);
     }
+    P2_ROLLED
+    for (int r = 4; r < 8; r++) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) s[i] = bb::pow7(bb::add(s[i], P3_RC16_EXT_FINAL_MONTY[r][i]));
+        for (int i = 0; i < 16; i++) s[i] = bb::sbox7_add(s[i], P2_RC.ext[r][i]);
         external_linear(s);
     }
 }

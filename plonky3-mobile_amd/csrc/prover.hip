@@ -313,6 +313,8 @@ struct FibProver::Impl {
     uint32_t *partials = nullptr, *small = nullptr, *qstage = nullptr, *qidx = nullptr;
     QTree* qtrees = nullptr;
     uint32_t* host_pinned = nullptr;  // pinned staging for small D2H reads
+    uint32_t* host_roots = nullptr;   // pinned + device-mapped: tree tops write their root here directly
+    uint32_t* dev_roots = nullptr;
     size_t host_pinned_words = 0;
     std::vector<void*> allocs;
     uint32_t n_rounds = 0;
@@ -323,6 +325,7 @@ struct FibProver::Impl {
     ~Impl() {
         for (void* p : allocs) (void)hipFree(p);
         if (host_pinned) (void)hipHostFree(host_pinned);
+        if (host_roots) (void)hipHostFree(host_roots);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
     int alloc(uint32_t** p, size_t words) {
@@ -376,6 +379,8 @@ int FibProver::init(uint32_t log_n, const FriParams& fp, hipStream_t stream, boo
     s.qtrees = reinterpret_cast<QTree*>(qt);
     s.host_pinned_words = std::max<size_t>((size_t)s.bary_blocks * 32, slot * std::max<uint32_t>(fp.num_queries, 1)) + 64;
     P3_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.host_pinned), s.host_pinned_words * 4));
+    P3_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.host_roots), 64 * 32, hipHostMallocMapped));
+    P3_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&s.dev_roots), s.host_roots, 0));
     // device descriptors of the trees opened per query (fixed for the prover's lifetime)
     std::vector<QTree> qd;
     uint32_t off = 0;
@@ -437,16 +442,16 @@ int FibProver::prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof) {
     const uint32_t* mp[1] = {s.lde_t};
     size_t hh[1] = {big}, ww[1] = {2};
     Tree* tp = nullptr;
-    if ((rc = mmcs_commit(st, mp, hh, ww, 1, &tp, s.layers_t))) return rc;
+    if ((rc = mmcs_commit(st, mp, hh, ww, 1, &tp, s.layers_t, s.dev_roots))) return rc;
     std::unique_ptr<Tree> tree_t(tp);
     // public values: first row and last right value
     uint32_t* hp = s.host_pinned;
-    P3_HIP(hipMemcpyAsync(hp, tree_t->layers + tree_t->layer_off.back(), 32, hipMemcpyDeviceToHost, st));
+    if (!tree_t->root_copied) P3_HIP(hipMemcpyAsync(s.host_roots, tree_t->layers + tree_t->layer_off.back(), 32, hipMemcpyDeviceToHost, st));
     P3_HIP(hipMemcpyAsync(hp + 8, s.trace, 8, hipMemcpyDeviceToHost, st));
     P3_HIP(hipMemcpyAsync(hp + 10, s.trace + 2 * (size_t)(n - 1) + 1, 4, hipMemcpyDeviceToHost, st));
     P3_HIP(hipStreamSynchronize(st));
     uint32_t root_t[8], pis[3] = {hp[8], hp[9], hp[10]};
-    memcpy(root_t, hp, 32);
+    memcpy(root_t, s.host_roots, 32);
     double t1 = now_ms();
     Challenger ch;
     ch.observe(bb::to_monty(log_n));
@@ -474,12 +479,12 @@ int FibProver::prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof) {
     }
     if ((rc = ntt_coset_lde(cx, st, s.qflat, s.lde_q, n, 4, s.fp.log_blowup, bb::ONE, true))) return rc;
     mp[0] = s.lde_q; ww[0] = 4;
-    if ((rc = mmcs_commit(st, mp, hh, ww, 1, &tp, s.layers_q))) return rc;
+    if ((rc = mmcs_commit(st, mp, hh, ww, 1, &tp, s.layers_q, s.dev_roots + 8))) return rc;
     std::unique_ptr<Tree> tree_q(tp);
     uint32_t root_q[8];
-    P3_HIP(hipMemcpyAsync(hp, tree_q->layers + tree_q->layer_off.back(), 32, hipMemcpyDeviceToHost, st));
+    if (!tree_q->root_copied) P3_HIP(hipMemcpyAsync(s.host_roots + 8, tree_q->layers + tree_q->layer_off.back(), 32, hipMemcpyDeviceToHost, st));
     P3_HIP(hipStreamSynchronize(st));
-    memcpy(root_q, hp, 32);
+    memcpy(root_q, s.host_roots + 8, 32);
     double t2 = now_ms();
     ch.observe_n(root_q, 8);
     Ext zeta = ch.sample_ext();
@@ -540,11 +545,12 @@ int FibProver::prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof) {
         uint32_t len = big >> r, half = len >> 1;
         mp[0] = s.fri_vec + s.fri_vec_off[r];
         hh[0] = half; ww[0] = 8;  // ExtensionMmcs: rows of two ext elements, flattened
-        if ((rc = mmcs_commit(st, mp, hh, ww, 1, &tp, s.fri_layers + s.fri_layer_off[r]))) return rc;
+        uint32_t slot = 16 + 8 * (r % 32);
+        if ((rc = mmcs_commit(st, mp, hh, ww, 1, &tp, s.fri_layers + s.fri_layer_off[r], s.dev_roots + slot))) return rc;
         ftrees.emplace_back(tp);
-        P3_HIP(hipMemcpyAsync(hp, tp->layers + tp->layer_off.back(), 32, hipMemcpyDeviceToHost, st));
+        if (!tp->root_copied) P3_HIP(hipMemcpyAsync(s.host_roots + slot, tp->layers + tp->layer_off.back(), 32, hipMemcpyDeviceToHost, st));
         P3_HIP(hipStreamSynchronize(st));
-        memcpy(&froots[(size_t)r * 8], hp, 32);
+        memcpy(&froots[(size_t)r * 8], s.host_roots + slot, 32);
         ch.observe_n(&froots[(size_t)r * 8], 8);
         Ext beta = ch.sample_ext();
         TwoLevelTable inv_roots;
@@ -591,9 +597,10 @@ int FibProver::prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof) {
         hp[16] = 0xffffffffu;
         P3_HIP(hipMemcpyAsync(s.small, hp, 68, hipMemcpyHostToDevice, st));
         uint32_t mask = (1u << s.fp.proof_of_work_bits) - 1u;
-        const uint32_t batch = 1u << 20;
+        // expected 2^bits candidates: first launch covers 4x that (P[miss] = e^-4), later ones 16x
+        uint32_t batch = 1u << std::min<uint32_t>(std::max<uint32_t>(s.fp.proof_of_work_bits + 2, 10), 24);
         uint32_t found = 0xffffffffu;
-        for (uint64_t base = 0; base < bb::P && found == 0xffffffffu; base += batch) {
+        for (uint64_t base = 0; base < bb::P && found == 0xffffffffu; base += batch, batch = std::min<uint32_t>(batch * 4, 1u << 24)) {
             hipLaunchKernelGGL(grind_kernel, dim3(batch / 256), dim3(256), 0, st, s.small, pos, mask, (uint32_t)base, s.small + 16);
             P3_HIP(hipGetLastError());
             P3_HIP(hipMemcpyAsync(hp + 32, s.small + 16, 4, hipMemcpyDeviceToHost, st));

@@ -98,17 +98,24 @@ class FibAirJob:
         return "fib_air 2^%d-row trace, BabyBear+Poseidon2, blowup %d (BASELINE configs[1])" % (
             self.log_height, 1 << self.log_blowup)
 
-    def step(self):
-        """Proves `batch` independent instances (a, b) = (first+i, first+i+1); returns the proof bytes."""
+    def step(self, instances=None):
+        """Proves independent instances; default: (a, b) = (first+i, first+i+1) for i < batch.
+        `instances`: list of (slot, a) as dealt by batch.scatter_descriptors.  Returns {slot: proof bytes}
+        as a list ordered by slot when called with the default."""
         jobs = queue.Queue()
-        for i in range(self.batch):
-            jobs.put((i, self.first + i))
+        todo = instances if instances is not None else [(i, self.first + i) for i in range(self.batch)]
+        for item in todo:
+            jobs.put(item)
         for w in self.workers:
             w.inbox.put(("prove", jobs))
-        res = [None] * self.batch
+        got = {}
         for w in self.workers:
             for i, pf in w.result():
-                res[i] = pf
+                got[i] = pf
+        if instances is not None:
+            self.last = got
+            return got
+        res = [got[i] for i in range(self.batch)]
         self.last = res
         return res
 

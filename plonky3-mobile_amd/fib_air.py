@@ -78,3 +78,101 @@ class FibAirProver:
             self.close()
         except Exception:
             pass
+
+
+# ---- the reference's DFT benchmark harness (native/src/fib_air.rs:77-222) -----------------------------
+_P = 0x78000001
+BENCHMARK_CASES = [(256, 8), (1024, 8), (4096, 8), (16384, 8), (4096, 32), (16384, 32), (4096, 64), (4096, 128),
+                   (16384, 64), (16384, 128), (256, 16000)]  # fib_air.rs:103-117
+
+
+def benchmark_input(height, width):
+    """fib_air.rs:77-86: v_i = (17 i + 3) mod P as BabyBear (Montgomery words), numpy uint32 (height, width)."""
+    import numpy as np
+    i = np.arange(height * width, dtype=np.uint64)
+    v = (i * np.uint64(17) + np.uint64(3)) % np.uint64(_P)
+    return ((v << np.uint64(32)) % np.uint64(_P)).astype(np.uint32).reshape(height, width)
+
+
+def percentile_ms(samples, q):
+    """fib_air.rs:88-96: nearest-rank percentile."""
+    import math
+    if not samples:
+        return 0.0
+    s = sorted(samples)
+    idx = min(max(int(math.ceil(q * len(s))) - 1, 0), len(s) - 1)
+    return s[idx]
+
+
+def run_dft_benchmark(cases=None, warmup=1, repeats=10, e2e_batch_size=4, cpu_dft=None):
+    """run_dft_benchmark (fib_air.rs:98-222) for the hip backend: per shape avg/median/p95 of
+      hip_e2e (host matrix in, host matrix out: upload + kernels + download + sync),
+      hip_e2e_batched (e2e_batch_size DFTs per synchronisation, per-DFT time),
+      hip_kernel (device resident, HIP events),
+    and — when `cpu_dft` (a callable matrix -> matrix, e.g. the test oracle) is given — the CPU column, the
+    speedups and the reference's equality check (fib_air.rs:193-196: mismatch is a hard error).
+    Returns (text report, list of per-shape dicts)."""
+    import time
+
+    import numpy as np
+    import torch
+
+    from .gpu_dft import BackendKind, GpuDft, dev_u32, host_u32, take_last_error
+    dft = GpuDft.with_backend(BackendKind.Hip)
+    lines = ["dft benchmark (repeats=%d, warmup=%d, stats=avg/median/p95)" % (repeats, warmup)]
+    rows = []
+
+    def stats(v):
+        return sum(v) / len(v), percentile_ms(v, 0.50), percentile_ms(v, 0.95)
+
+    for h, w in (cases or BENCHMARK_CASES):
+        x = benchmark_input(h, w)
+        xd = dev_u32(x)
+        take_last_error()
+        for _ in range(warmup):
+            dft.dft_batch(x)
+            dft.dft_batch(xd)
+        e2e, out = [], None
+        for _ in range(repeats):
+            t = time.perf_counter()
+            out = dft.dft_batch(x)
+            e2e.append((time.perf_counter() - t) * 1e3)
+        batched = []
+        pinned_in = torch.from_numpy(x.view(np.int32)).pin_memory()
+        outs = [torch.empty((h, w), dtype=torch.int32).pin_memory() for _ in range(e2e_batch_size)]
+        for _ in range(repeats):
+            t = time.perf_counter()
+            for k in range(e2e_batch_size):
+                d = pinned_in.to("cuda", non_blocking=True)
+                outs[k].copy_(dft.dft_batch(d), non_blocking=True)
+            torch.cuda.synchronize()
+            batched.append((time.perf_counter() - t) * 1e3 / e2e_batch_size)
+        kern = []
+        for _ in range(repeats):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            yd = dft.dft_batch(xd)
+            e.record()
+            torch.cuda.synchronize()
+            kern.append(s.elapsed_time(e))
+        if take_last_error() is not None:
+            raise RuntimeError("hip benchmark error at h=%d, w=%d" % (h, w))
+        row = {"h": h, "w": w, "hip_e2e": stats(e2e), "hip_e2e_batched": stats(batched), "hip_kernel": stats(kern)}
+        line = "h=%d, w=%d:" % (h, w)
+        if cpu_dft is not None:
+            cpu, cpu_out = [], None
+            for _ in range(max(1, min(repeats, 3))):
+                t = time.perf_counter()
+                cpu_out = cpu_dft(x)
+                cpu.append((time.perf_counter() - t) * 1e3)
+            if not (np.array_equal(cpu_out, out) and np.array_equal(cpu_out, host_u32(yd))):
+                raise RuntimeError("dft benchmark mismatch at h=%d, w=%d" % (h, w))
+            row["cpu"] = stats(cpu)
+            line += " cpu(avg=%.3f med=%.3f p95=%.3f)ms" % row["cpu"]
+        for key in ("hip_e2e", "hip_e2e_batched", "hip_kernel"):
+            line += " %s(avg=%.3f med=%.3f p95=%.3f)ms" % ((key,) + row[key])
+            if cpu_dft is not None:
+                line += " speedup_%s(avg)=%.2fx" % (key[4:], row["cpu"][0] / row[key][0] if row[key][0] > 0 else 0.0)
+        lines.append(line)
+        rows.append(row)
+    return "\n".join(lines), rows

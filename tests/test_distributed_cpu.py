@@ -1,0 +1,61 @@
+"""world_size-2 gloo test (CPU) of the multi-GPU batch plumbing: descriptor scatter, instance sharding and
+proof gather.  The proving itself needs a GPU; here each rank 'proves' with a deterministic stand-in so the
+collective layout is what is under test."""
+import os
+import socket
+import sys
+
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _fake_proof(i, a, b):
+    return (b"proof-%d-%d-%d|" % (i, a, b)) * (3 + i % 4)  # ragged lengths
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_package
+    load_package()
+    from plonky3_mobile_amd import batch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    instances = [(i, i + 1) for i in range(7)] if rank == 0 else []
+    mine = batch.scatter_descriptors(instances)
+    assert [i for i, _, _ in mine] == batch.shard_instances(7, rank, world)
+    local = [(i, _fake_proof(i, a, b)) for i, a, b in mine]
+    allp = batch.gather_proofs(local, 7)
+    if rank == 0:
+        q.put(allp)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_scatter_prove_gather_world2():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    allp = q.get(timeout=120)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert allp == [_fake_proof(i, i, i + 1) for i in range(7)]
+
+
+def test_shard_instances_partition():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_package
+    load_package()
+    from plonky3_mobile_amd import batch
+    for world in (1, 2, 4, 8):
+        got = sorted(i for r in range(world) for i in batch.shard_instances(64, r, world))
+        assert got == list(range(64))
+        assert all(len(batch.shard_instances(64, r, world)) == 64 // world for r in range(world))

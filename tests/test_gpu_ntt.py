@@ -153,3 +153,16 @@ def test_error_paths(dft, p3):
         p3.GpuDft.with_backend(p3.BackendKind.Cpu).dft_batch(np.zeros((4, 2), np.uint32))
     # empty matrices are a no-op
     assert dft.dft_batch(np.zeros((0, 2), np.uint32)).shape == (0, 2)
+
+
+def test_keccak_air_shaped_wide_matrix(dft, oracle, p3):
+    """BASELINE configs[4] shape family: width 2633 (Keccak-f AIR trace width), non power of two, wider than a
+    tile run; LDE + commitment parity on a short instance (the 2^16-row size is exercised by tools/kernel_bench)."""
+    rng = np.random.default_rng(2633)
+    x = _rand(rng, 1 << 7, 2633)
+    exp = oracle.coset_lde_batch(x, 1, p3.GENERATOR_MONTY, True)
+    got = dft.coset_lde_batch(x, 1, p3.GENERATOR_MONTY, bit_reversed_out=True)
+    assert np.array_equal(got, exp)
+    root, _ = p3.MerkleTreeMmcs().commit([got])
+    oroot, _ = oracle.mmcs_commit([exp])
+    assert np.array_equal(root, oroot)

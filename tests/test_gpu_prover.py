@@ -86,3 +86,24 @@ def test_bad_parameters(p3):
         p3.FibAirProver(0)
     with pytest.raises(p3.P3HipError):
         p3.FibAirProver(27, params=p3.FriParameters(log_blowup=2))
+
+
+def test_cfg3_2_24_blowup4_verifies(p3, oracle):
+    """BASELINE configs[2]: 2^24-row trace, blowup 4 ("FRI-fold-heavy").  A CPU oracle proof of this size takes
+    minutes, so parity here is the size-independent property: the oracle's verifier accepts the GPU proof and
+    rejects it for a different public value."""
+    gfp, ofp = _fp(p3, oracle, 2, 0, 50, 8)
+    pr = p3.FibAirProver(24, params=gfp)
+    proof = pr.prove(0, 1)
+    x = oracle.fib_public_x(0, 1, 1 << 24)
+    assert oracle.verify_fib_air(proof, 0, 1, x, 24, ofp) == 0
+    assert oracle.verify_fib_air(proof, 0, 1, x + 1, 24, ofp) != 0
+    pr.close()
+
+
+def test_dft_benchmark_harness(p3, oracle):
+    """run_dft_benchmark (fib_air.rs:98-222) incl. the reference's equality check against the CPU path."""
+    text, rows = p3.run_dft_benchmark(cases=[(256, 8), (4096, 32), (256, 1000)], repeats=3, cpu_dft=oracle.dft_batch)
+    assert text.startswith("dft benchmark (repeats=3, warmup=1, stats=avg/median/p95)")
+    assert len(rows) == 3 and all(r["hip_kernel"][0] > 0 for r in rows)
+    assert p3.percentile_ms([3.0, 1.0, 2.0, 4.0], 0.95) == 4.0 and p3.percentile_ms([], 0.5) == 0.0

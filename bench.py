@@ -64,10 +64,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
+    n_dev = torch.cuda.device_count()
+    torch.cuda.set_device(local_rank % max(n_dev, 1))
+    # backend "nccl" IS RCCL on ROCm.  P3HIP_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with
+    # fewer GPUs than ranks (collectives then move host tensors).
+    backend = os.environ.get("P3HIP_BENCH_BACKEND", "nccl")
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     ok, msg = p3.is_available()
     if not ok:
         raise RuntimeError("no HIP backend, refusing to run a fallback: " + msg)
@@ -92,9 +100,9 @@ def main():
         # BASELINE configs[3]: rank 0 scatters the instance descriptors, every rank proves its shard
         # (instance i -> rank i mod world), the proof bytes are gathered back on rank 0.  No other collective.
         inst = [(k * n_total + i, k * n_total + i + 1) for i in range(n_total)] if rank == 0 else []
-        mine = pbatch.scatter_descriptors(inst, device="cuda")
+        mine = pbatch.scatter_descriptors(inst, device=coll_dev)
         got = job.step([(i, a) for i, a, _ in mine])
-        return pbatch.gather_proofs(sorted(got.items()), n_total, device="cuda")
+        return pbatch.gather_proofs(sorted(got.items()), n_total, device=coll_dev)
 
     for k in range(args.warmup):
         one_step(k)
@@ -105,7 +113,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     units = args.batch * args.steps * world
@@ -113,6 +121,16 @@ def main():
 
     # ---- roofline of the dominant HBM-bound unit: the coset LDE, HIP events on the launch stream ----
     roof = job.lde_roofline(reps=20)
+    traffic, traffic_src = None, None
+    try:  # HBM-side bytes of the same LDE unit from the committed PMC passes (not collected live)
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_lde.json")) as f:
+            pmc = json.load(f)
+        key = {(20, 1): "cfg2_lde_2^20x2_blowup2", (24, 2): "cfg3_lde_2^24x2_blowup4"}.get((args.log_height, args.log_blowup))
+        if key:
+            traffic = pmc[key]["total_bytes"]
+            traffic_src = "profiles/r01_pmc_lde.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, summed over the unit's launches"
+    except Exception:
+        pass
     out = {
         "metric": job.metric_name(),
         "value": value,
@@ -133,7 +151,7 @@ def main():
                            "proof_of_work_bits": job.params.proof_of_work_bits},
                    "parallelism": "independent proofs, instance i -> rank i mod N; RCCL only scatters descriptors / gathers proof bytes"},
         "roofline": {"bound": "hbm", "achieved": roof["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": roof["gbps"] / HBM_PEAK_GBPS, "traffic": None,
+                     "frac": roof["gbps"] / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "coset_lde_batch (ntt_pass_kernel launches)", "algorithmic_bytes": roof["bytes"],
                      "avg_us": roof["avg_us"], "batched_gbps": roof.get("batched_gbps")},
         "stages_ms": job.stage_breakdown(),

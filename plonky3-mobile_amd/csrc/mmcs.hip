@@ -11,6 +11,7 @@
 #include "mmcs.h"
 #include "poseidon2.cuh"
 #include "poseidon2_coop.cuh"
+#include "poseidon2_f64.cuh"
 
 namespace p3 {
 
@@ -196,7 +197,29 @@ __global__ void poseidon2_permute_kernel(uint32_t* states, uint64_t n) {
     for (int k = 0; k < 4; k++) q[k] = make_uint4(s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]);
 }
 
+__global__ void poseidon2_permute_f64_kernel(uint32_t* states, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s[16];
+    uint4* q = reinterpret_cast<uint4*>(states + i * 16);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint4 v = q[k];
+        s[4 * k] = p2f::load_elem(v.x); s[4 * k + 1] = p2f::load_elem(v.y); s[4 * k + 2] = p2f::load_elem(v.z); s[4 * k + 3] = p2f::load_elem(v.w);
+    }
+    p2f::permute(s);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        q[k] = make_uint4(p2f::store_elem(s[4 * k]), p2f::store_elem(s[4 * k + 1]), p2f::store_elem(s[4 * k + 2]), p2f::store_elem(s[4 * k + 3]));
+}
+
 int poseidon2_permute_states(hipStream_t stream, uint32_t* d_states, uint64_t n) {
+    static int use_f64 = [] { const char* e = getenv("P3HIP_P2_F64"); return e ? atoi(e) : 0; }();
+    if (n && use_f64) {
+        hipLaunchKernelGGL(poseidon2_permute_f64_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_states, n);
+        P3_HIP(hipGetLastError());
+        return OK;
+    }
     if (!n) return OK;
     hipLaunchKernelGGL(poseidon2_permute_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_states, n);
     P3_HIP(hipGetLastError());

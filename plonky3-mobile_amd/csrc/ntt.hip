@@ -496,7 +496,9 @@ int launch_pass_t(hipStream_t stream, const PassArgs& a, uint32_t blocks) {
 
 int launch_pass(hipStream_t stream, PassArgs& a) {
     // geometry
+    static int force_run = [] { const char* e = getenv("P3HIP_NTT_LOGRUN"); return e ? atoi(e) : 0; }();
     uint32_t log_run = a.b >= 11 ? 4 : 5;
+    if (force_run == 3 && a.W <= 8 && a.b >= 8) log_run = 3;  // narrow matrices: small tiles, many workgroups
     uint32_t RUN = 1u << log_run;
     a.wshift = is_pow2(a.W) ? log2u(a.W) : 0xffffffffu;
     uint64_t blocks;
@@ -519,6 +521,7 @@ int launch_pass(hipStream_t stream, PassArgs& a) {
     }
     if (blocks > 0x7fffffffull) return fail(ERR_BAD_ARG, "ntt: matrix too large for one launch");
     uint32_t nb = (uint32_t)blocks;
+    if (log_run == 3) return launch_pass_t<3, 5>(stream, a, nb);
     if (log_run == 4) return launch_pass_t<4, 5>(stream, a, nb);
     uint32_t log_r = a.b >= 10 ? 5 : (a.b >= 4 ? 4 : a.b);
     switch (log_r) {

@@ -46,6 +46,18 @@ KERNEL(k_pkaddf32, "v_pk_add_f32 %4, %4, %9\n v_pk_add_f32 %5, %5, %9\n v_pk_add
 KERNEL(k_mad64, "v_mad_u64_u32 %4, vcc, %0, %8, %4\n v_mad_u64_u32 %5, vcc, %1, %8, %5\n v_mad_u64_u32 %6, vcc, %2, %8, %6\n v_mad_u64_u32 %7, vcc, %3, %8, %7", "memory" COMMA "vcc")
 KERNEL(k_dpp, "v_mov_b32_dpp %0, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %3 row_ror:4 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %0 row_ror:4 row_mask:0xf bank_mask:0xf", "memory")
 
+KERNEL(k_cndmask, "v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc", "memory")
+KERNEL(k_subco, "v_sub_co_u32 %0, vcc, %0, %8\n v_sub_co_u32 %1, vcc, %1, %8\n v_sub_co_u32 %2, vcc, %2, %8\n v_sub_co_u32 %3, vcc, %3, %8", "memory" COMMA "vcc")
+KERNEL(k_addco, "v_add_co_u32 %0, vcc, %0, %8\n v_add_co_u32 %1, vcc, %1, %8\n v_add_co_u32 %2, vcc, %2, %8\n v_add_co_u32 %3, vcc, %3, %8", "memory" COMMA "vcc")
+KERNEL(k_cmp, "v_cmp_lt_u32 vcc, %0, %8\n v_cmp_lt_u32 vcc, %1, %8\n v_cmp_lt_u32 vcc, %2, %8\n v_cmp_lt_u32 vcc, %3, %8", "memory" COMMA "vcc")
+KERNEL(k_max, "v_max_u32 %0, %0, %8\n v_max_u32 %1, %1, %8\n v_max_u32 %2, %2, %8\n v_max_u32 %3, %3, %8", "memory")
+KERNEL(k_xor, "v_xor_b32 %0, %0, %8\n v_xor_b32 %1, %1, %8\n v_xor_b32 %2, %2, %8\n v_xor_b32 %3, %3, %8", "memory")
+KERNEL(k_mov, "v_mov_b32 %0, %8\n v_mov_b32 %1, %8\n v_mov_b32 %2, %8\n v_mov_b32 %3, %8", "memory")
+KERNEL(k_ashr, "v_ashrrev_i32 %0, 3, %0\n v_ashrrev_i32 %1, 3, %1\n v_ashrrev_i32 %2, 3, %2\n v_ashrrev_i32 %3, 3, %3", "memory")
+KERNEL(k_subrev, "v_subrev_u32 %0, %8, %0\n v_subrev_u32 %1, %8, %1\n v_subrev_u32 %2, %8, %2\n v_subrev_u32 %3, %8, %3", "memory")
+KERNEL(k_mini, "v_min_i32 %0, %0, %8\n v_min_i32 %1, %1, %8\n v_min_i32 %2, %2, %8\n v_min_i32 %3, %3, %8", "memory")
+KERNEL(k_addlit, "v_add_u32 %0, 0x87ffffff, %0\n v_add_u32 %1, 0x87ffffff, %1\n v_add_u32 %2, 0x87ffffff, %2\n v_add_u32 %3, 0x87ffffff, %3", "memory")
+
 template <class K>
 void run(const char* name, K kern, uint64_t* d, int waves_per_simd) {
     // blocks of 256 threads (4 waves = 1 per SIMD); waves_per_simd blocks per CU on all 256 CUs.  Wall clock
@@ -69,7 +81,7 @@ void run(const char* name, K kern, uint64_t* d, int waves_per_simd) {
 int main() {
     uint64_t* d;
     hipMalloc(&d, 64);
-    for (int w : {1, 2, 8}) {
+    for (int w : {8}) {
         run("v_add_u32", k_add, d, w); run("v_sub_u32", k_sub, d, w); run("v_min_u32", k_min, d, w); run("v_and_b32", k_and, d, w);
         run("v_add3_u32", k_add3, d, w); run("v_lshlrev", k_lshl, d, w); run("v_lshl_add", k_lshladd, d, w);
         run("v_mul_lo_u32", k_mullo, d, w); run("v_mul_hi_u32", k_mulhi, d, w); run("v_mul_hi_i32", k_mulhii, d, w);
@@ -78,6 +90,8 @@ int main() {
         run("v_add_f64", k_addf64, d, w); run("v_mul_f64", k_mulf64, d, w); run("v_fma_f64", k_fmaf64, d, w);
         run("v_rndne_f64", k_rndf64, d, w); run("v_cvt_f64_u32", k_cvtf64u, d, w); run("v_cvt_u32_f64", k_cvtuf64, d, w);
         run("v_mov_dpp", k_dpp, d, w);
+        run("v_cndmask_b32", k_cndmask, d, w); run("v_sub_co_u32", k_subco, d, w); run("v_add_co_u32", k_addco, d, w); run("v_cmp_lt_u32", k_cmp, d, w);
+        run("v_max_u32", k_max, d, w); run("v_xor_b32", k_xor, d, w); run("v_mov_b32", k_mov, d, w); run("v_ashrrev_i32", k_ashr, d, w); run("v_subrev_u32", k_subrev, d, w); run("v_min_i32", k_mini, d, w); run("v_add_u32 literal", k_addlit, d, w);
         printf("\n");
     }
     return 0;

@@ -1,0 +1,173 @@
+// C++ host-side mirror of the reference's Rust interfaces for the hip backend, header-only over the C ABI
+// (include/p3hip.h).  Names, argument meaning and error behaviour follow the reference:
+//   BackendKind / set_backend_kind[_from_str] / get_backend_kind / take_last_error   native/src/gpu_dft.rs:14-68
+//   GpuDft::{default, with_backend, dft_batch} + Plonky3's provided idft/coset methods     native/src/gpu_dft.rs:70-115
+//   RowMajorMatrix (p3_matrix::dense): row-major values + width
+//   benchmark_input / percentile_ms / generate_trace_rows                                   native/src/fib_air.rs:77-96,266-284
+//   MerkleTreeMmcs (Mmcs::commit / open_batch) and FibAirProver (prove)                      native/src/fib_air.rs:40-70
+// Rust's `Result<_, String>` becomes p3hip::Error (thrown); there is NO CPU fallback here — the reference's
+// GpuDft falls back to Radix2DitParallel on Err (gpu_dft.rs:100-112); a C++ caller catches and decides.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "p3hip.h"
+
+namespace p3hip {
+
+constexpr uint32_t P = 0x78000001u;
+constexpr uint32_t MONTY_ONE = 0x0ffffffeu;
+constexpr uint32_t GENERATOR_MONTY = (uint32_t)((31ull << 32) % P);  // Val::GENERATOR
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+inline std::string take_last_error() {  // gpu_dft.rs:65-68
+    const char* m = p3hip_take_last_error();
+    return m ? std::string(m) : std::string();
+}
+inline void check(int rc) {
+    if (rc != 0) throw Error(rc, take_last_error());
+}
+
+enum class BackendKind : int { Cpu = 0, Vulkan = 1, Metal = 2, WebGpu = 3, Hip = 4 };  // gpu_dft.rs:14-40
+inline void set_backend_kind_from_str(const std::string& v) {                             // gpu_dft.rs:53-63
+    if (p3hip_set_backend(v.c_str()) != 0) throw Error(P3HIP_ERR_BACKEND, take_last_error());
+}
+inline BackendKind get_backend_kind() { return (BackendKind)p3hip_get_backend(); }       // gpu_dft.rs:49-51
+inline std::pair<bool, std::string> is_available() {                                      // lib.rs:167-179
+    char buf[256];
+    int rc = p3hip_is_available(buf, sizeof buf);
+    if (rc != 0) (void)p3hip_take_last_error();
+    return {rc == 0, std::string(buf)};
+}
+inline uint32_t to_monty(uint64_t canon) { return (uint32_t)(((canon % P) << 32) % P); }
+
+struct RowMajorMatrix {  // p3_matrix::dense::RowMajorMatrix<BabyBear>, values are Montgomery words
+    std::vector<uint32_t> values;
+    size_t width = 0;
+    RowMajorMatrix() = default;
+    RowMajorMatrix(std::vector<uint32_t> v, size_t w) : values(std::move(v)), width(w) {}
+    size_t height() const { return width ? values.size() / width : 0; }
+};
+
+class GpuDft {  // gpu_dft.rs:70-115
+  public:
+    GpuDft() : backend_(get_backend_kind()) {}  // Default (gpu_dft.rs:76-83)
+    static GpuDft with_backend(BackendKind b) { GpuDft d; d.backend_ = b; return d; }  // gpu_dft.rs:86-92
+    BackendKind backend() const { return backend_; }
+    RowMajorMatrix dft_batch(const RowMajorMatrix& m) const {
+        require_hip();
+        RowMajorMatrix out(std::vector<uint32_t>(m.values.size()), m.width);
+        check(p3hip_dft_batch_bb31(m.values.data(), out.values.data(), m.height(), m.width));
+        return out;
+    }
+    RowMajorMatrix idft_batch(const RowMajorMatrix& m) const {
+        require_hip();
+        RowMajorMatrix out(std::vector<uint32_t>(m.values.size()), m.width);
+        check(p3hip_idft_batch_bb31(m.values.data(), out.values.data(), m.height(), m.width));
+        return out;
+    }
+    RowMajorMatrix coset_dft_batch(const RowMajorMatrix& m, uint32_t shift_monty) const {
+        require_hip();
+        RowMajorMatrix out(std::vector<uint32_t>(m.values.size()), m.width);
+        check(p3hip_coset_dft_batch_bb31(m.values.data(), out.values.data(), m.height(), m.width, shift_monty));
+        return out;
+    }
+    RowMajorMatrix coset_lde_batch(const RowMajorMatrix& m, unsigned added_bits, uint32_t shift_monty,
+                                   bool bit_reversed_out = false) const {
+        require_hip();
+        RowMajorMatrix out(std::vector<uint32_t>(m.values.size() << added_bits), m.width);
+        check(p3hip_coset_lde_batch_bb31(m.values.data(), out.values.data(), m.height(), m.width, added_bits,
+                                         shift_monty, bit_reversed_out ? 1 : 0));
+        return out;
+    }
+
+  private:
+    void require_hip() const {
+        if (backend_ != BackendKind::Hip)
+            throw Error(P3HIP_ERR_BACKEND, "only the hip backend runs here (the CPU path is the caller's Radix2DitParallel)");
+    }
+    BackendKind backend_;
+};
+
+// fib_air.rs:77-86
+inline RowMajorMatrix benchmark_input(size_t height, size_t width) {
+    std::vector<uint32_t> v(height * width);
+    for (size_t i = 0; i < v.size(); i++) v[i] = to_monty(((uint64_t)i * 17 + 3) % P);
+    return RowMajorMatrix(std::move(v), width);
+}
+// fib_air.rs:88-96 (nearest rank)
+inline double percentile_ms(std::vector<double> s, double q) {
+    if (s.empty()) return 0.0;
+    std::sort(s.begin(), s.end());
+    size_t idx = (size_t)std::ceil(q * (double)s.size());
+    idx = idx ? idx - 1 : 0;
+    return s[std::min(idx, s.size() - 1)];
+}
+
+class MerkleTree {  // prover data: device matrices + digest layers owned by the library
+  public:
+    MerkleTree() = default;
+    MerkleTree(const MerkleTree&) = delete;
+    MerkleTree(MerkleTree&& o) noexcept : h_(o.h_), widths_(std::move(o.widths_)) { o.h_ = nullptr; }
+    ~MerkleTree() { if (h_) p3hip_mmcs_free(h_); }
+    size_t log_max_height() const { return p3hip_mmcs_log_max_height(h_); }
+    p3hip_tree_t* h_ = nullptr;
+    std::vector<size_t> widths_;
+};
+class MerkleTreeMmcs {  // Mmcs<BabyBear> with the Poseidon2 hashes (fib_air.rs:40-51 wires the Keccak flavour)
+  public:
+    std::pair<std::vector<uint32_t>, MerkleTree> commit(const std::vector<RowMajorMatrix>& mats) const {
+        std::vector<const uint32_t*> ptrs;
+        std::vector<size_t> hs, ws;
+        for (auto& m : mats) { ptrs.push_back(m.values.data()); hs.push_back(m.height()); ws.push_back(m.width); }
+        std::vector<uint32_t> root(8);
+        MerkleTree t;
+        check(p3hip_mmcs_commit(ptrs.data(), hs.data(), ws.data(), mats.size(), root.data(), &t.h_));
+        t.widths_ = ws;
+        return {std::move(root), std::move(t)};
+    }
+    // -> (opened rows per matrix, sibling digests)
+    std::pair<std::vector<std::vector<uint32_t>>, std::vector<uint32_t>> open_batch(size_t index, const MerkleTree& t) const {
+        size_t tot = 0;
+        for (size_t w : t.widths_) tot += w;
+        std::vector<uint32_t> rows(tot ? tot : 1), path(t.log_max_height() * 8 + 8);
+        check(p3hip_mmcs_open_batch(t.h_, index, rows.data(), path.data(), nullptr));
+        std::vector<std::vector<uint32_t>> out;
+        size_t off = 0;
+        for (size_t w : t.widths_) { out.emplace_back(rows.begin() + off, rows.begin() + off + w); off += w; }
+        path.resize(t.log_max_height() * 8);
+        return {std::move(out), std::move(path)};
+    }
+};
+
+struct FriParameters {  // p3_fri::FriParameters; defaults = create_benchmark_fri_params
+    uint32_t log_blowup = 1, log_final_poly_len = 0, num_queries = 100, proof_of_work_bits = 16;
+};
+class FibAirProver {  // prove(&config, &FibonacciAir{}, generate_trace_rows(a, b, n), &pis), fib_air.rs:61-70
+  public:
+    FibAirProver(unsigned log_n, FriParameters fp = FriParameters()) {
+        p3hip_fri_params_t c{fp.log_blowup, fp.log_final_poly_len, fp.num_queries, fp.proof_of_work_bits};
+        check(p3hip_fib_prover_create(log_n, &c, nullptr, 1, &h_));
+    }
+    FibAirProver(const FibAirProver&) = delete;
+    ~FibAirProver() { if (h_) p3hip_fib_prover_destroy(h_); }
+    std::vector<uint8_t> prove(uint64_t a, uint64_t b) {
+        const uint8_t* p = nullptr;
+        size_t n = 0;
+        check(p3hip_fib_prover_prove(h_, a, b, &p, &n));
+        return std::vector<uint8_t>(p, p + n);
+    }
+
+  private:
+    p3hip_fib_prover_t* h_ = nullptr;
+};
+
+}  // namespace p3hip

@@ -7,6 +7,8 @@
 //            layer's length are hashed row-wise and compressed in (compress_and_inject); all layers stay
 //            in HBM for open_batch.
 // One permutation per lane, state in VGPRs; digests are 32-byte records read/written as 2 x dwordx4.
+#include <algorithm>
+
 #include "common.h"
 #include "mmcs.h"
 #include "poseidon2.cuh"
@@ -146,42 +148,39 @@ __global__ void __launch_bounds__(256) leaf_coop_kernel(const uint32_t* mat, uin
     }
     if (act && lane16 < 8) digests[(size_t)r * 8 + lane16] = v;
 }
-// All remaining (injection-free) levels of a tree whose current layer has n0 <= 1024 digests, one workgroup
-// of 1024 lanes = 64 cooperative rows; the current layer lives in LDS, every layer is also written to HBM.
-__global__ void __launch_bounds__(1024) tree_top_coop_kernel(uint32_t* layer0, uint32_t n0, uint32_t* root_copy) {
-    __shared__ uint32_t lds[1024 * 8];
+// `levels` (<= 7) consecutive injection-free tree levels in ONE launch: each workgroup owns a chunk of up to
+// 128 consecutive digests of layer `layer_in` (n_in digests, a power of two), keeps its shrinking layer in LDS
+// and writes every intermediate layer to its place in HBM (layers are stored back to back).  16 lanes per
+// permutation; waves whose four lane-rows are all idle at a level skip the permutation.  When the last
+// level produces the root it is also written to `root_copy` (host-mapped) if given.
+__global__ void __launch_bounds__(1024) tree_levels_coop_kernel(uint32_t* layer_in, uint32_t n_in, uint32_t levels,
+                                                                uint32_t* root_copy) {
+    __shared__ uint32_t lds[128 * 8];
     const uint32_t tid = threadIdx.x, lane16 = tid & 15, grp = tid >> 4;
     const p2c::LaneConst lc = p2c::lane_constants(lane16);
-    for (uint32_t i = tid; i < n0 * 8; i += blockDim.x) lds[i] = layer0[i];
+    const uint32_t chunk = n_in < 128u ? n_in : 128u;
+    const uint32_t* src = layer_in + (size_t)blockIdx.x * chunk * 8;
+    for (uint32_t i = tid; i < chunk * 8; i += blockDim.x) lds[i] = src[i];
     __syncthreads();
-    uint32_t* out = layer0 + (size_t)n0 * 8;
-    for (uint32_t n = n0; n > 1; n >>= 1) {
-        const uint32_t half = n >> 1;
-        // batches of 64 permutations; results are held until every batch of the level has read its inputs
-        uint32_t res[8];
-        const uint32_t nb = (half + 63) >> 6;  // <= 8
-#pragma unroll
-        for (uint32_t bi = 0; bi < 8; bi++) {
-            if (bi < nb) {
-                uint32_t i = bi * 64 + grp;
-                uint32_t v = i < half ? lds[i * 16 + lane16] : 0u;
-                res[bi] = p2c::permute(v, lc);
-            }
+    uint32_t* out = layer_in + (size_t)n_in * 8;  // start of the next layer
+    uint32_t cur_n = n_in;
+    for (uint32_t l = 0; l < levels; l++) {
+        const uint32_t half = chunk >> (l + 1);          // permutations of this workgroup at this level
+        const bool wave_active = ((tid >> 6) << 2) < half;  // first lane-row of this wave
+        uint32_t res = 0;
+        if (wave_active) {
+            uint32_t v = grp < half ? lds[grp * 16 + lane16] : 0u;
+            res = p2c::permute(v, lc);
         }
         __syncthreads();
-#pragma unroll
-        for (uint32_t bi = 0; bi < 8; bi++) {
-            if (bi < nb) {
-                uint32_t i = bi * 64 + grp;
-                if (i < half && lane16 < 8) {
-                    lds[i * 8 + lane16] = res[bi];
-                    out[(size_t)i * 8 + lane16] = res[bi];
-                    if (half == 1 && root_copy) root_copy[lane16] = res[bi];  // host-mapped: no D2H copy needed
-                }
-            }
+        if (grp < half && lane16 < 8) {
+            lds[grp * 8 + lane16] = res;
+            out[((size_t)blockIdx.x * half + grp) * 8 + lane16] = res;
+            if (cur_n == 2 && root_copy) root_copy[lane16] = res;  // this level produced the root
         }
         __syncthreads();
-        out += (size_t)half * 8;
+        cur_n >>= 1;
+        out += (size_t)cur_n * 8;
     }
 }
 
@@ -264,15 +263,16 @@ static RowSet make_rowset(const Tree& t, uint64_t h) {
     return rs;
 }
 
+static bool has_height(const Tree& t, uint64_t h) {
+    for (size_t m = 0; m < t.mats.size(); m++)
+        if (t.heights[m] == h) return true;
+    return false;
+}
+
 Tree::~Tree() {
     if (layers && owns_layers) (void)hipFree(layers);
     if (staging) (void)hipFree(staging);
     for (void* p : owned) (void)hipFree(p);
-}
-
-static uint32_t top_digests() {
-    static uint32_t v = [] { const char* e = getenv("P3HIP_TREE_TOP"); uint32_t x = e ? (uint32_t)atoi(e) : 64u; return x < 2 ? 2u : (x > 1024 ? 1024u : x); }();
-    return v;
 }
 
 int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t* heights, const size_t* widths,
@@ -321,27 +321,31 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
         }
         P3_HIP(hipGetLastError());
     }
-    for (size_t l = 1; l < t->layer_len.size(); l++) {
+    for (size_t l = 1; l < t->layer_len.size();) {
         uint64_t len = t->layer_len[l];
         RowSet rs = make_rowset(*t, len);
         bool inject = rs.count > 0;
-        bool more_inject = false;
-        for (size_t i = 0; i < n_mats; i++) more_inject |= heights[i] <= len;
-        if (!more_inject && t->layer_len[l - 1] <= top_digests()) {
-            uint32_t n0 = (uint32_t)t->layer_len[l - 1];
-            hipLaunchKernelGGL(tree_top_coop_kernel, dim3(1), dim3(1024), 0, stream, t->layers + t->layer_off[l - 1], n0, root_copy);
-            t->root_copied = root_copy != nullptr;
-            P3_HIP(hipGetLastError());
-            break;
-        }
         if (!inject && len < COOP_MAX) {
-            hipLaunchKernelGGL(compress_coop_kernel, dim3((uint32_t)((len * 16 + 255) / 256)), dim3(256), 0, stream,
-                               t->layers + t->layer_off[l - 1], t->layers + t->layer_off[l], (uint32_t)len);
-        } else {
-            hipLaunchKernelGGL(compress_layer_kernel, dim3((uint32_t)((len + 255) / 256)), dim3(256), 0, stream,
-                               t->layers + t->layer_off[l - 1], t->layers + t->layer_off[l], len, rs, inject ? 1u : 0u);
+            // as many injection-free levels as one launch may take (<= 7, stop before the next injected layer)
+            uint32_t levels = 0;
+            while (levels < 7 && l + levels < t->layer_len.size() && !has_height(*t, t->layer_len[l + levels])) levels++;
+            uint64_t n_in = t->layer_len[l - 1];
+            uint32_t chunk = n_in < 128 ? (uint32_t)n_in : 128u;
+            while ((1u << levels) > chunk) levels--;
+            uint32_t blocks = (uint32_t)(n_in / chunk);
+            uint32_t threads = std::max<uint32_t>(64, chunk * 8);
+            bool makes_root = t->layer_len[l + levels - 1] == 1;
+            hipLaunchKernelGGL(tree_levels_coop_kernel, dim3(blocks), dim3(threads), 0, stream, t->layers + t->layer_off[l - 1],
+                               (uint32_t)n_in, levels, makes_root ? root_copy : nullptr);
+            P3_HIP(hipGetLastError());
+            if (makes_root) t->root_copied = root_copy != nullptr;
+            l += levels;
+            continue;
         }
+        hipLaunchKernelGGL(compress_layer_kernel, dim3((uint32_t)((len + 255) / 256)), dim3(256), 0, stream,
+                           t->layers + t->layer_off[l - 1], t->layers + t->layer_off[l], len, rs, inject ? 1u : 0u);
         P3_HIP(hipGetLastError());
+        l++;
     }
     *out = t.release();
     return OK;

@@ -128,7 +128,9 @@ static void put_path(buf_t *b, const uint32_t *path, size_t n) { put_u32(b, (uin
 /* p3_uni_stark::prove for FibonacciAir.  Returns malloc'd proof bytes. */
 int p3o_prove_fib_air(uint64_t a, uint64_t b, unsigned log_n, unsigned log_blowup, unsigned log_final_poly_len,
                       unsigned num_queries, unsigned pow_bits, uint8_t **out, size_t *out_len) {
-    if (log_n < 1 || log_n + log_blowup > BB_TWO_ADICITY || log_final_poly_len + log_blowup > log_n + log_blowup) return -1;
+    if (log_n < 1 || log_blowup < 1 || log_n + log_blowup > BB_TWO_ADICITY || log_final_poly_len > log_n) return -1;
+    /* p3_fri::prover::prove: if log_final_poly_len > 0, log_min_height > log_final_poly_len + log_blowup */
+    if (log_final_poly_len > 0 && log_final_poly_len >= log_n) return -1;
     const size_t n = (size_t)1 << log_n, big = n << log_blowup;
     const unsigned log_big = log_n + log_blowup;
     const uint32_t gen = bb_to_monty(BB_GENERATOR_CANON);

@@ -250,8 +250,10 @@ __device__ __forceinline__ bool colside_addr(const PassArgs& a, uint32_t kind, u
     return true;
 }
 
+// Thread count is 2^b * RUN / R: at most 1024 for the wide-run instances, 256 for the RUN = 8 instance (which
+// may then keep all 32 elements of a radix-32 round in registers without spilling).
 template <int LOG_RUN, int LOG_R>
-__global__ void __launch_bounds__(1024) ntt_pass_kernel(PassArgs a) {
+__global__ void __launch_bounds__(LOG_RUN == 3 ? 256 : 1024) ntt_pass_kernel(PassArgs a) {
     constexpr uint32_t RUN = 1u << LOG_RUN, STRIDE = RUN + 1;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t b = a.b, npts = 1u << b;
@@ -480,7 +482,7 @@ int launch_pass_t(hipStream_t stream, const PassArgs& a, uint32_t blocks) {
     uint32_t npts = 1u << a.b;
     uint32_t threads = (npts * RUN) >> LOG_R;
     if (threads < 64) threads = 64;
-    if (threads > 1024) return fail(ERR_INTERNAL, "ntt: tile needs more than 1024 threads");
+    if (threads > (LOG_RUN == 3 ? 256u : 1024u)) return fail(ERR_INTERNAL, "ntt: tile needs more threads than the kernel's launch bound");
     size_t lds = (size_t)npts * (RUN + 1) * 4 + (size_t)npts * 4;
     auto kern = ntt_pass_kernel<LOG_RUN, LOG_R>;
     static bool attr_set = false;
@@ -498,7 +500,7 @@ int launch_pass(hipStream_t stream, PassArgs& a) {
     // geometry
     static int force_run = [] { const char* e = getenv("P3HIP_NTT_LOGRUN"); return e ? atoi(e) : 0; }();
     uint32_t log_run = a.b >= 11 ? 4 : 5;
-    if (force_run == 3 && a.W <= 8 && a.b >= 8) log_run = 3;  // narrow matrices: small tiles, many workgroups
+    if (force_run == 3 && a.W <= 8 && a.b >= 8 && a.b <= 10) log_run = 3;  // narrow matrices: small tiles, many workgroups
     uint32_t RUN = 1u << log_run;
     a.wshift = is_pow2(a.W) ? log2u(a.W) : 0xffffffffu;
     uint64_t blocks;

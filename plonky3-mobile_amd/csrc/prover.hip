@@ -344,7 +344,9 @@ int FibProver::init(uint32_t log_n, const FriParams& fp, hipStream_t stream, boo
     if (log_n + fp.log_blowup > bb::TWO_ADICITY || log_n + fp.log_blowup > 31)
         return fail(ERR_BAD_ARG, "fib prover: LDE height exceeds two-adicity");
     if (fp.log_blowup < 1) return fail(ERR_BAD_ARG, "fib prover: log_blowup must be >= 1");
-    if (fp.log_final_poly_len > log_n) return fail(ERR_BAD_ARG, "fib prover: final polynomial longer than the trace");
+    // p3_fri::prover::prove: `if log_final_poly_len > 0 { assert!(log_min_height > log_final_poly_len + log_blowup) }`
+    if (fp.log_final_poly_len > log_n || (fp.log_final_poly_len > 0 && fp.log_final_poly_len >= log_n))
+        return fail(ERR_BAD_ARG, "fib prover: log_final_poly_len must be below the trace's log height");
     if (fp.proof_of_work_bits > 30) return fail(ERR_BAD_ARG, "fib prover: proof_of_work_bits too large");
     s.log_n = log_n; s.fp = fp; s.log_big = log_n + fp.log_blowup;
     s.stream = stream; s.own_stream = own_stream;
@@ -377,7 +379,8 @@ int FibProver::init(uint32_t log_n, const FriParams& fp, hipStream_t stream, boo
     uint32_t* qt = nullptr;
     if ((rc = s.alloc(&qt, (sizeof(QTree) / 4) * (s.n_rounds + 2)))) return rc;
     s.qtrees = reinterpret_cast<QTree*>(qt);
-    s.host_pinned_words = std::max<size_t>((size_t)s.bary_blocks * 32, slot * std::max<uint32_t>(fp.num_queries, 1)) + 64;
+    s.host_pinned_words = std::max<size_t>(std::max<size_t>((size_t)s.bary_blocks * 32, slot * std::max<uint32_t>(fp.num_queries, 1)),
+                                           (size_t)4 << fp.log_final_poly_len) + 64;
     P3_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.host_pinned), s.host_pinned_words * 4));
     P3_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.host_roots), 64 * 32, hipHostMallocMapped));
     P3_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&s.dev_roots), s.host_roots, 0));

@@ -29,7 +29,8 @@ def test_proof_bytes_equal_oracle(p3, oracle, log_n):
     pr.close()
 
 
-@pytest.mark.parametrize("t", [(1, 0, 100, 16), (2, 0, 10, 4), (2, 2, 6, 5), (1, 3, 9, 0), (3, 1, 4, 10)])
+@pytest.mark.parametrize("t", [(1, 0, 100, 16), (2, 0, 10, 4), (2, 2, 6, 5), (1, 3, 9, 0), (3, 1, 4, 10), (1, 0, 0, 0),
+                               (1, 8, 3, 2), (4, 0, 2, 1)])
 def test_fri_parameter_variants(p3, oracle, t):
     gfp, ofp = _fp(p3, oracle, *t)
     pr = p3.FibAirProver(9, params=gfp)
@@ -81,9 +82,14 @@ def test_concurrent_provers_on_threads(p3, oracle):
         assert out[i][0] == ref and out[i][1] == ref
 
 
-def test_bad_parameters(p3):
+def test_bad_parameters(p3, oracle):
     with pytest.raises(p3.P3HipError):
         p3.FibAirProver(0)
+    # upstream asserts log_min_height > log_final_poly_len + log_blowup when log_final_poly_len > 0
+    with pytest.raises(p3.P3HipError):
+        p3.FibAirProver(9, params=p3.FriParameters(1, 9, 3, 2))
+    with pytest.raises(ValueError):
+        oracle.prove_fib_air(0, 1, 9, oracle.FriParams(1, 9, 3, 2))
     with pytest.raises(p3.P3HipError):
         p3.FibAirProver(27, params=p3.FriParameters(log_blowup=2))
 

@@ -49,6 +49,8 @@ struct PassArgs {
     uint32_t sc_T;
     uint32_t has_us;    // multiply stored value by uscale
     uint32_t uscale;
+    uint32_t sc_step;   // fast DIF kernel: shift^(rows between a lane's consecutive loads)
+    uint32_t sc_base;   // the scale table's base (shift), host side only
 };
 
 __device__ __forceinline__ uint32_t rev_bits(uint32_t v, uint32_t bits) {
@@ -120,6 +122,10 @@ __device__ __forceinline__ uint32_t two_level(const uint32_t* lo, const uint32_t
     uint32_t h = hi[(uint32_t)(e >> T)];
     return bb::mul(l, h);
 }
+
+}  // namespace p3
+#include "ntt_fast.cuh"
+namespace p3 {
 
 // Decodes a copy-loop index into tile coordinates (pt, x), the global word offset and the natural row
 // index for one side of the pass.  Returns false when the slot is padding (outside the matrix).
@@ -252,8 +258,17 @@ __device__ __forceinline__ bool colside_addr(const PassArgs& a, uint32_t kind, u
 
 // Thread count is 2^b * RUN / R: at most 1024 for the wide-run instances, 256 for the RUN = 8 instance (which
 // may then keep all 32 elements of a radix-32 round in registers without spilling).
-template <int LOG_RUN, int LOG_R>
+// MODE fixes (load side, store side, direction, twiddle) at compile time so the five pass shapes the plans use
+// shed every other path; MODE 0 keeps them as run-time values (rare shapes).
+//   1 DIT first (gather, STRIDED -> GROUP_REV)   2 DIT later (INPLACE, pre-twiddle)
+//   3 DIF non-last (INPLACE, post-twiddle)       4 DIF last, bit-reversed out (GROUP -> GROUP)
+//   5 DIF last, natural out (GROUP_REV -> STRIDED)
+template <int LOG_RUN, int LOG_R, int MODE>
 __global__ void __launch_bounds__(LOG_RUN == 3 ? 256 : 1024) ntt_pass_kernel(PassArgs a) {
+    const uint32_t load_kind = MODE == 0 ? a.load_kind : (MODE == 1 ? (uint32_t)SIDE_STRIDED : (MODE == 2 || MODE == 3) ? (uint32_t)SIDE_INPLACE : MODE == 4 ? (uint32_t)SIDE_GROUP : (uint32_t)SIDE_GROUP_REV);
+    const uint32_t store_kind = MODE == 0 ? a.store_kind : (MODE == 1 ? (uint32_t)SIDE_GROUP_REV : (MODE == 2 || MODE == 3) ? (uint32_t)SIDE_INPLACE : MODE == 4 ? (uint32_t)SIDE_GROUP : (uint32_t)SIDE_STRIDED);
+    const uint32_t dif = MODE == 0 ? a.dif : (MODE >= 3 ? 1u : 0u);
+    const uint32_t has_tw = MODE == 0 ? a.has_tw : ((MODE == 2 || MODE == 3) ? 1u : 0u);
     constexpr uint32_t RUN = 1u << LOG_RUN, STRIDE = RUN + 1;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t b = a.b, npts = 1u << b;
@@ -279,24 +294,24 @@ __global__ void __launch_bounds__(LOG_RUN == 3 ? 256 : 1024) ntt_pass_kernel(Pas
     const bool full = nth == (total >> LOG_R);  // one slot per (thread, j): the unrolled fast paths apply
     const uint32_t xr = tid & (RUN - 1), pt0 = tid >> LOG_RUN, dpt = nth >> LOG_RUN;
     // ---- load ----
-    if (full && side_is_rowwise<RUN>(a, a.load_kind)) {
-        const RowSide rs = rowside_init<RUN>(a, a.load_kind, xr, hi, h0, c0, f0);
+    if (full && side_is_rowwise<RUN>(a, load_kind)) {
+        const RowSide rs = rowside_init<RUN>(a, load_kind, xr, hi, h0, c0, f0);
         uint32_t v[R];
 #pragma unroll
         for (uint32_t j = 0; j < R; j++) {
             uint64_t word, row;
-            rowside_addr(a, a.load_kind, rs, pt0 + j * dpt, word, row);
+            rowside_addr(a, load_kind, rs, pt0 + j * dpt, word, row);
             v[j] = (rs.valid && row < a.src_rows) ? a.src[word] : 0u;
         }
         if (a.has_sc) {
 #pragma unroll
             for (uint32_t j = 0; j < R; j++) {
                 uint64_t word, row;
-                rowside_addr(a, a.load_kind, rs, pt0 + j * dpt, word, row);
+                rowside_addr(a, load_kind, rs, pt0 + j * dpt, word, row);
                 if (rs.valid && row < a.src_rows) v[j] = bb::mul(v[j], two_level(a.sc_lo, a.sc_hi, a.sc_T, row));
             }
         }
-        if (a.has_tw && !a.dif) {
+        if (has_tw && !dif) {
 #pragma unroll
             for (uint32_t j = 0; j < R; j++)
                 v[j] = bb::mul(v[j], two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)rev_bits(pt0 + j * dpt, b) * rs.lo));
@@ -310,7 +325,7 @@ __global__ void __launch_bounds__(LOG_RUN == 3 ? 256 : 1024) ntt_pass_kernel(Pas
         for (uint32_t j = 0; j < R; j++) {
             uint32_t pt, x;
             uint64_t word, row;
-            bool ok = colside_addr(a, a.load_kind, tid + j * nth, h0, pt, x, word, row);
+            bool ok = colside_addr(a, load_kind, tid + j * nth, h0, pt, x, word, row);
             v[j] = (ok && row < a.src_rows) ? a.src[word] : 0u;
         }
         if (a.has_sc) {
@@ -318,7 +333,7 @@ __global__ void __launch_bounds__(LOG_RUN == 3 ? 256 : 1024) ntt_pass_kernel(Pas
             for (uint32_t j = 0; j < R; j++) {
                 uint32_t pt, x;
                 uint64_t word, row;
-                if (colside_addr(a, a.load_kind, tid + j * nth, h0, pt, x, word, row) && row < a.src_rows)
+                if (colside_addr(a, load_kind, tid + j * nth, h0, pt, x, word, row) && row < a.src_rows)
                     v[j] = bb::mul(v[j], two_level(a.sc_lo, a.sc_hi, a.sc_T, row));
             }
         }
@@ -326,23 +341,23 @@ __global__ void __launch_bounds__(LOG_RUN == 3 ? 256 : 1024) ntt_pass_kernel(Pas
         for (uint32_t j = 0; j < R; j++) {
             uint32_t pt, x;
             uint64_t word, row;
-            if (colside_addr(a, a.load_kind, tid + j * nth, h0, pt, x, word, row)) tile[pt * STRIDE + x] = v[j];
+            if (colside_addr(a, load_kind, tid + j * nth, h0, pt, x, word, row)) tile[pt * STRIDE + x] = v[j];
         }
     } else {
         for (uint32_t idx = tid; idx < total; idx += nth) {
             uint32_t pt, x, lo;
             uint64_t word, row;
-            bool ok = decode_side<RUN>(a, a.load_kind, idx, hi, h0, c0, f0, pt, x, word, row, lo);
+            bool ok = decode_side<RUN>(a, load_kind, idx, hi, h0, c0, f0, pt, x, word, row, lo);
             uint32_t v = 0;
             if (ok) {
                 if (row < a.src_rows) {
                     v = a.src[word];
                     if (a.has_sc) v = bb::mul(v, two_level(a.sc_lo, a.sc_hi, a.sc_T, row));
                 }
-                if (a.has_tw && !a.dif)
+                if (has_tw && !dif)
                     v = bb::mul(v, two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)rev_bits(pt, b) * lo));
                 tile[pt * STRIDE + x] = v;
-            } else if (a.load_kind == SIDE_INPLACE || !(a.W < RUN && a.load_kind != SIDE_STRIDED)) {
+            } else if (load_kind == SIDE_INPLACE || !(a.W < RUN && load_kind != SIDE_STRIDED)) {
                 tile[pt * STRIDE + x] = 0;  // row-wise decode: (pt, x) are valid tile coordinates even for padding
             }
         }
@@ -352,7 +367,7 @@ __global__ void __launch_bounds__(LOG_RUN == 3 ? 256 : 1024) ntt_pass_kernel(Pas
     // ---- b stages as register-radix rounds ----
     const uint32_t nwork = total >> LOG_R;
     const uint32_t x = xr, g = pt0;
-    if (!a.dif) {
+    if (!dif) {
         for (uint32_t k0 = 0; k0 < b;) {
             uint32_t rr = (b - k0) < (uint32_t)LOG_R ? (b - k0) : (uint32_t)LOG_R;
             if (tid < nwork) radix_round_dispatch<LOG_R, false>(rr, tile, twl, STRIDE, b, k0, x, g);
@@ -369,13 +384,13 @@ __global__ void __launch_bounds__(LOG_RUN == 3 ? 256 : 1024) ntt_pass_kernel(Pas
     }
 
     // ---- store ----
-    if (full && side_is_rowwise<RUN>(a, a.store_kind)) {
-        const RowSide rs = rowside_init<RUN>(a, a.store_kind, xr, hi, h0, c0, f0);
+    if (full && side_is_rowwise<RUN>(a, store_kind)) {
+        const RowSide rs = rowside_init<RUN>(a, store_kind, xr, hi, h0, c0, f0);
         if (!rs.valid) return;
         uint32_t v[R];
 #pragma unroll
         for (uint32_t j = 0; j < R; j++) v[j] = tile[(pt0 + j * dpt) * STRIDE + xr];
-        if (a.has_tw && a.dif) {
+        if (has_tw && dif) {
 #pragma unroll
             for (uint32_t j = 0; j < R; j++)
                 v[j] = bb::mul(v[j], two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)rev_bits(pt0 + j * dpt, b) * rs.lo));
@@ -387,7 +402,7 @@ __global__ void __launch_bounds__(LOG_RUN == 3 ? 256 : 1024) ntt_pass_kernel(Pas
 #pragma unroll
         for (uint32_t j = 0; j < R; j++) {
             uint64_t word, row;
-            rowside_addr(a, a.store_kind, rs, pt0 + j * dpt, word, row);
+            rowside_addr(a, store_kind, rs, pt0 + j * dpt, word, row);
             a.dst[word] = v[j];
         }
         return;
@@ -398,7 +413,7 @@ __global__ void __launch_bounds__(LOG_RUN == 3 ? 256 : 1024) ntt_pass_kernel(Pas
         for (uint32_t j = 0; j < R; j++) {
             uint32_t pt, x;
             uint64_t word, row;
-            bool ok = colside_addr(a, a.store_kind, tid + j * nth, h0, pt, x, word, row);
+            bool ok = colside_addr(a, store_kind, tid + j * nth, h0, pt, x, word, row);
             v[j] = ok ? tile[pt * STRIDE + x] : 0u;
         }
         if (a.has_us) {
@@ -409,16 +424,16 @@ __global__ void __launch_bounds__(LOG_RUN == 3 ? 256 : 1024) ntt_pass_kernel(Pas
         for (uint32_t j = 0; j < R; j++) {
             uint32_t pt, x;
             uint64_t word, row;
-            if (colside_addr(a, a.store_kind, tid + j * nth, h0, pt, x, word, row)) a.dst[word] = v[j];
+            if (colside_addr(a, store_kind, tid + j * nth, h0, pt, x, word, row)) a.dst[word] = v[j];
         }
         return;
     }
     for (uint32_t idx = tid; idx < total; idx += nth) {
         uint32_t pt, xx, lo;
         uint64_t word, row;
-        if (!decode_side<RUN>(a, a.store_kind, idx, hi, h0, c0, f0, pt, xx, word, row, lo)) continue;
+        if (!decode_side<RUN>(a, store_kind, idx, hi, h0, c0, f0, pt, xx, word, row, lo)) continue;
         uint32_t v = tile[pt * STRIDE + xx];
-        if (a.has_tw && a.dif)
+        if (has_tw && dif)
             v = bb::mul(v, two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)rev_bits(pt, b) * lo));
         if (a.has_us) v = bb::mul(v, a.uscale);
         a.dst[word] = v;
@@ -476,15 +491,15 @@ std::vector<uint32_t> split_digits(uint32_t n) {
     return d;
 }
 
-template <int LOG_RUN, int LOG_R>
-int launch_pass_t(hipStream_t stream, const PassArgs& a, uint32_t blocks) {
+template <int LOG_RUN, int LOG_R, int MODE>
+int launch_pass_m(hipStream_t stream, const PassArgs& a, uint32_t blocks) {
     constexpr uint32_t RUN = 1u << LOG_RUN;
     uint32_t npts = 1u << a.b;
     uint32_t threads = (npts * RUN) >> LOG_R;
     if (threads < 64) threads = 64;
     if (threads > (LOG_RUN == 3 ? 256u : 1024u)) return fail(ERR_INTERNAL, "ntt: tile needs more threads than the kernel's launch bound");
     size_t lds = (size_t)npts * (RUN + 1) * 4 + (size_t)npts * 4;
-    auto kern = ntt_pass_kernel<LOG_RUN, LOG_R>;
+    auto kern = ntt_pass_kernel<LOG_RUN, LOG_R, MODE>;
     static bool attr_set = false;
     if (!attr_set) {
         P3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -494,6 +509,75 @@ int launch_pass_t(hipStream_t stream, const PassArgs& a, uint32_t blocks) {
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, stream, a);
     P3_HIP(hipGetLastError());
     return OK;
+}
+
+inline int pass_mode(const PassArgs& a) {
+    if (!a.dif && a.load_kind == SIDE_STRIDED && a.store_kind == SIDE_GROUP_REV && !a.has_tw) return 1;
+    if (!a.dif && a.load_kind == SIDE_INPLACE && a.store_kind == SIDE_INPLACE && a.has_tw) return 2;
+    if (a.dif && a.load_kind == SIDE_INPLACE && a.store_kind == SIDE_INPLACE && a.has_tw) return 3;
+    if (a.dif && a.load_kind == SIDE_GROUP && a.store_kind == SIDE_GROUP && !a.has_tw) return 4;
+    if (a.dif && a.load_kind == SIDE_GROUP_REV && a.store_kind == SIDE_STRIDED && !a.has_tw) return 5;
+    return 0;
+}
+// specialised shapes only for the tile geometries the plans actually pick; everything else runs MODE 0
+template <int LOG_RUN, int LOG_R, bool FAST>
+int launch_pass_t(hipStream_t stream, const PassArgs& a, uint32_t blocks) {
+    if constexpr (FAST) {
+        switch (pass_mode(a)) {
+            case 1: return launch_pass_m<LOG_RUN, LOG_R, 1>(stream, a, blocks);
+            case 2: return launch_pass_m<LOG_RUN, LOG_R, 2>(stream, a, blocks);
+            case 3: return launch_pass_m<LOG_RUN, LOG_R, 3>(stream, a, blocks);
+            case 4: return launch_pass_m<LOG_RUN, LOG_R, 4>(stream, a, blocks);
+            case 5: return launch_pass_m<LOG_RUN, LOG_R, 5>(stream, a, blocks);
+            default: break;
+        }
+    }
+    return launch_pass_m<LOG_RUN, LOG_R, 0>(stream, a, blocks);
+}
+
+template <int B, int MODE>
+int launch_fast_t(hipStream_t stream, const PassArgs& a, uint32_t blocks) {
+    constexpr uint32_t NPTS = 1u << B;
+    size_t lds = (size_t)NPTS * 33 * 4 + (size_t)NPTS * 4;
+    hipLaunchKernelGGL((ntt_fast_kernel<B, MODE>), dim3(blocks), dim3(NPTS * 2), lds, stream, a);
+    P3_HIP(hipGetLastError());
+    return OK;
+}
+template <int B, int MODE>
+int launch_fast_group_t(hipStream_t stream, const PassArgs& a, uint32_t blocks) {
+    constexpr uint32_t NPTS = 1u << B;
+    size_t lds = (size_t)NPTS * 33 * 4 + (size_t)NPTS * 4;
+    hipLaunchKernelGGL((ntt_fast_group_kernel<B, MODE>), dim3(blocks), dim3(NPTS * 2), lds, stream, a);
+    P3_HIP(hipGetLastError());
+    return OK;
+}
+int launch_fast(hipStream_t stream, const PassArgs& a, uint32_t blocks, int mode) {
+    if (mode == 1) {
+        switch (a.b) {
+            case 6: return launch_fast_group_t<6, 1>(stream, a, blocks);
+            case 7: return launch_fast_group_t<7, 1>(stream, a, blocks);
+            default: return launch_fast_group_t<8, 1>(stream, a, blocks);
+        }
+    }
+    if (mode == 4) {
+        switch (a.b) {
+            case 6: return launch_fast_group_t<6, 4>(stream, a, blocks);
+            case 7: return launch_fast_group_t<7, 4>(stream, a, blocks);
+            default: return launch_fast_group_t<8, 4>(stream, a, blocks);
+        }
+    }
+    if (mode == 2) {
+        switch (a.b) {
+            case 6: return launch_fast_t<6, 2>(stream, a, blocks);
+            case 7: return launch_fast_t<7, 2>(stream, a, blocks);
+            default: return launch_fast_t<8, 2>(stream, a, blocks);
+        }
+    }
+    switch (a.b) {
+        case 6: return launch_fast_t<6, 3>(stream, a, blocks);
+        case 7: return launch_fast_t<7, 3>(stream, a, blocks);
+        default: return launch_fast_t<8, 3>(stream, a, blocks);
+    }
 }
 
 int launch_pass(hipStream_t stream, PassArgs& a) {
@@ -523,15 +607,25 @@ int launch_pass(hipStream_t stream, PassArgs& a) {
     }
     if (blocks > 0x7fffffffull) return fail(ERR_BAD_ARG, "ntt: matrix too large for one launch");
     uint32_t nb = (uint32_t)blocks;
-    if (log_run == 3) return launch_pass_t<3, 5>(stream, a, nb);
-    if (log_run == 4) return launch_pass_t<4, 5>(stream, a, nb);
+    static int use_fast = [] { const char* e = getenv("P3HIP_NTT_FAST"); return e ? atoi(e) : 1; }();
+    if (use_fast && log_run == 5 && a.b >= 6 && a.b <= 8) {
+        int mode = pass_mode(a);
+        if (mode == 2 || mode == 3) {
+            if (mode == 3 && a.has_sc) a.sc_step = bb::pow(a.sc_base, (uint64_t)((1u << a.b) / 16) << a.s0);
+            return launch_fast(stream, a, nb, mode);
+        }
+        // group-side passes: narrow widths must be powers of two for the shift-based column-wise copy
+        if ((mode == 1 || (mode == 4 && !a.has_sc)) && (a.W >= 32 || a.wshift != 0xffffffffu)) return launch_fast(stream, a, nb, mode);
+    }
+    if (log_run == 3) return launch_pass_t<3, 5, false>(stream, a, nb);
+    if (log_run == 4) return launch_pass_t<4, 5, false>(stream, a, nb);
     uint32_t log_r = a.b >= 10 ? 5 : (a.b >= 4 ? 4 : a.b);
     switch (log_r) {
-        case 5: return launch_pass_t<5, 5>(stream, a, nb);
-        case 4: return launch_pass_t<5, 4>(stream, a, nb);
-        case 3: return launch_pass_t<5, 3>(stream, a, nb);
-        case 2: return launch_pass_t<5, 2>(stream, a, nb);
-        default: return launch_pass_t<5, 1>(stream, a, nb);
+        case 5: return launch_pass_t<5, 5, false>(stream, a, nb);
+        case 4: return launch_pass_t<5, 4, true>(stream, a, nb);
+        case 3: return launch_pass_t<5, 3, false>(stream, a, nb);
+        case 2: return launch_pass_t<5, 2, false>(stream, a, nb);
+        default: return launch_pass_t<5, 1, false>(stream, a, nb);
     }
 }
 
@@ -570,7 +664,7 @@ int run_dit(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* dst,
 // DIF plan: natural in (first src_rows rows, zero padded to 2^n, optionally scaled per row) ->
 // bit-reversed (in place layout) or natural (scattered by the last pass) out.
 int run_dif(Context& cx, hipStream_t stream, const uint32_t* src, uint64_t src_rows, uint32_t* dst, uint32_t n,
-            uint32_t W, bool inverse, const TwoLevelTable* sc, bool natural_out) {
+            uint32_t W, bool inverse, const TwoLevelTable* sc, uint32_t sc_base, bool natural_out) {
     std::vector<uint32_t> digits = split_digits(n);  // lowest first; DIF walks them top-down
     uint32_t s0 = n;
     for (size_t ii = digits.size(); ii-- > 0;) {
@@ -582,7 +676,7 @@ int run_dif(Context& cx, hipStream_t stream, const uint32_t* src, uint64_t src_r
         a.src = first ? src : dst;
         a.dst = dst;
         a.src_rows = first ? src_rows : (1ull << n);
-        if (first && sc) { a.has_sc = 1; a.sc_lo = sc->lo; a.sc_hi = sc->hi; a.sc_T = sc->T; }
+        if (first && sc) { a.has_sc = 1; a.sc_lo = sc->lo; a.sc_hi = sc->hi; a.sc_T = sc->T; a.sc_base = sc_base; }
         if (!last) { a.load_kind = SIDE_INPLACE; a.store_kind = SIDE_INPLACE; }
         else if (natural_out) { a.load_kind = SIDE_GROUP_REV; a.store_kind = SIDE_STRIDED; }
         else { a.load_kind = SIDE_GROUP; a.store_kind = SIDE_GROUP; }
@@ -631,7 +725,7 @@ int ntt_coset_dft(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t
         return OK;
     }
     if (src == dst) return fail(ERR_BAD_ARG, "coset_dft: in-place not supported");
-    return run_dif(cx, stream, src, height, dst, n, width, false, &sc, true);
+    return run_dif(cx, stream, src, height, dst, n, width, false, &sc, shift, true);
 }
 
 int ntt_coset_lde(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* dst, uint64_t height,
@@ -661,7 +755,7 @@ int ntt_coset_lde(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t
     uint32_t hinv = bb::inv(bb::to_monty((uint32_t)height));
     rc = cx.get_scale_table(shift, n, hinv, &sc);
     if (rc) return rc;
-    return run_dif(cx, stream, coeffs, height, dst, m, width, false, &sc, !bit_reversed_out);
+    return run_dif(cx, stream, coeffs, height, dst, m, width, false, &sc, shift, !bit_reversed_out);
 }
 
 }  // namespace p3

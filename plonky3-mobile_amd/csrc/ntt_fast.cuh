@@ -1,0 +1,356 @@
+// Lean pass kernels for the in-place (strided-run) passes of the NTT plans: the shapes that carry most of the
+// LDE's work (two of the three passes in each direction).  Compared with the general ntt_pass_kernel:
+//   * tile size is a template parameter (B = 6, 7 or 8 stages = radix-16 round + radix-2^(B-4) round);
+//   * the first round runs on the registers the global loads land in and the last round stores straight from
+//     registers: ONE LDS exchange and ONE barrier per pass instead of three;
+//   * per-thread addressing is a base pointer plus compile-time multiples of one row stride;
+//   * the inter-pass twiddles w^(rev(pt) * lo) of a thread's 16 rows are c * phi^r (r = 0..15): two table
+//     look-ups per thread and a doubling ladder, instead of two look-ups per element.
+// Included by ntt.hip (needs PassArgs, two_level, rev_bits).
+#pragma once
+
+namespace p3 {
+
+__device__ __forceinline__ constexpr uint32_t crev(uint32_t v, uint32_t bits) {
+    uint32_t r = 0;
+    for (uint32_t i = 0; i < bits; i++) r |= ((v >> i) & 1u) << (bits - 1 - i);
+    return r;
+}
+
+// pw[r] = c * phi^r for r < N (N a power of two), by doubling: N + log2(N) - 1 products, short chains.
+template <int N>
+__device__ __forceinline__ void power_ladder(uint32_t c, uint32_t phi, uint32_t (&pw)[N]) {
+    pw[0] = c;
+    uint32_t step = phi;
+#pragma unroll
+    for (int len = 1; len < N; len <<= 1) {
+#pragma unroll
+        for (int i = 0; i < len; i++) pw[len + i] = bb::mul(pw[i], step);
+        if (len * 2 < N) step = bb::sqr(step);
+    }
+}
+
+// MODE 2: DIT, in place, pre-twiddle (+ optional uniform scale on store).
+// MODE 3: DIF, in place, post-twiddle (+ optional per-row scale and zero padding on load).
+template <int B, int MODE>
+__global__ void __launch_bounds__(512) ntt_fast_kernel(PassArgs a) {
+    constexpr uint32_t RUN = 32, STRIDE = 33, NPTS = 1u << B, NTH = NPTS * 2, GSPAN = NPTS / 16;
+    constexpr int RR2 = B - 4;             // stages of the short round
+    constexpr uint32_t NSUB = 1u << (4 - RR2), SUB2 = 1u << RR2;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* tile = smem;
+    uint32_t* twl = smem + NPTS * STRIDE;
+    const uint32_t tid = threadIdx.x, x = tid & 31, g = tid >> 5;
+    for (uint32_t i = tid; i + 1 < NPTS; i += NTH) twl[i] = a.tile_tw[i];
+
+    const uint32_t bid = blockIdx.x;
+    const uint32_t hi = bid / a.n_inner;
+    const uint64_t f = (uint64_t)(bid % a.n_inner) * RUN + x;
+    const bool valid = f < ((uint64_t)a.W << a.s0);
+    const uint32_t lo = a.wshift != 0xffffffffu ? (uint32_t)(f >> a.wshift) : (uint32_t)(f / a.W);
+    const uint64_t stride = (uint64_t)a.W << a.s0;  // words between consecutive tile rows
+    const uint64_t base = ((uint64_t)hi << (a.s0 + B)) * a.W + f;
+    uint32_t v[16];
+
+    if constexpr (MODE == 2) {
+        // ---- load rows pt = 16 g + j, pre-twiddle w^(rev_B(pt) * lo) ----
+        const uint32_t* p = a.src + base + (uint64_t)(g * 16) * stride;
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) v[j] = valid ? p[j * stride] : 0u;
+        {
+            uint32_t c = two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)lo * rev_bits(g, B - 4));
+            uint32_t phi = two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)lo << (B - 4));
+            uint32_t pw[16];
+            power_ladder<16>(c, phi, pw);
+#pragma unroll
+            for (uint32_t j = 0; j < 16; j++) v[j] = bb::mul(v[j], pw[crev(j, 4)]);
+        }
+        __syncthreads();  // twl ready
+        // ---- round 1: stages 0..3 on registers ----
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+#pragma unroll
+            for (uint32_t j0 = 0; j0 < 16; j0++) {
+                if (j0 & (1u << u)) continue;
+                const uint32_t j1 = j0 | (1u << u);
+                const uint32_t w = twl[(1u << u) - 1u + (j0 & ((1u << u) - 1u))];
+                uint32_t t = bb::mul(v[j1], w), s = v[j0];
+                v[j0] = bb::add(s, t);
+                v[j1] = bb::sub(s, t);
+            }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) tile[(g * 16 + j) * STRIDE + x] = v[j];
+        __syncthreads();
+        // ---- round 2: stages 4..B-1; pt = (ji << 4) | o, o = js * GSPAN + g ----
+#pragma unroll
+        for (uint32_t js = 0; js < NSUB; js++) {
+            const uint32_t o = js * GSPAN + g;
+#pragma unroll
+            for (uint32_t ji = 0; ji < SUB2; ji++) v[js * SUB2 + ji] = tile[((ji << 4) | o) * STRIDE + x];
+#pragma unroll
+            for (int u = 0; u < RR2; u++) {
+                const uint32_t k = 4 + u;
+#pragma unroll
+                for (uint32_t ji = 0; ji < SUB2; ji++) {
+                    if (ji & (1u << u)) continue;
+                    const uint32_t j0 = js * SUB2 + ji, j1 = j0 | (1u << u);
+                    const uint32_t w = twl[(1u << k) - 1u + ((ji & ((1u << u) - 1u)) << 4) + o];
+                    uint32_t t = bb::mul(v[j1], w), s = v[j0];
+                    v[j0] = bb::add(s, t);
+                    v[j1] = bb::sub(s, t);
+                }
+            }
+        }
+        if (!valid) return;
+        uint32_t* q = a.dst + base;
+#pragma unroll
+        for (uint32_t js = 0; js < NSUB; js++)
+#pragma unroll
+            for (uint32_t ji = 0; ji < SUB2; ji++) {
+                uint32_t val = v[js * SUB2 + ji];
+                if (a.has_us) val = bb::mul(val, a.uscale);
+                q[(uint64_t)((ji << 4) | (js * GSPAN + g)) * stride] = val;
+            }
+    } else {
+        // ---- DIF: load rows pt = (j << (B-4)) | g (zero padding / row scale on the first forward pass) ----
+        const uint64_t row0 = ((uint64_t)hi << (a.s0 + B)) + ((uint64_t)g << a.s0) + lo;
+        const uint64_t drow = (uint64_t)GSPAN << a.s0;  // rows between consecutive j
+        const uint32_t* p = a.src + base + (uint64_t)g * stride;
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) v[j] = (valid && row0 + j * drow < a.src_rows) ? p[(uint64_t)(j * GSPAN) * stride] : 0u;
+        if (a.has_sc && valid && row0 < a.src_rows) {
+            // sc(row) = mult * shift^row: c_j = sc(row0) * (shift^drow)^j
+            uint32_t c = two_level(a.sc_lo, a.sc_hi, a.sc_T, row0);
+            uint32_t pw[16];
+            power_ladder<16>(c, a.sc_step, pw);
+#pragma unroll
+            for (uint32_t j = 0; j < 16; j++) v[j] = bb::mul(v[j], pw[j]);  // rows beyond src_rows hold 0 already
+        }
+        __syncthreads();  // twl ready
+        // ---- round A: stages B-1..B-4 on registers (k0 = B-4, low bits of pt = g) ----
+#pragma unroll
+        for (int u = 3; u >= 0; u--) {
+            const uint32_t k = (B - 4) + u;
+#pragma unroll
+            for (uint32_t j0 = 0; j0 < 16; j0++) {
+                if (j0 & (1u << u)) continue;
+                const uint32_t j1 = j0 | (1u << u);
+                const uint32_t w = twl[(1u << k) - 1u + ((j0 & ((1u << u) - 1u)) << (B - 4)) + g];
+                uint32_t s = v[j0], c = v[j1];
+                v[j0] = bb::add(s, c);
+                v[j1] = bb::mul(bb::sub(s, c), w);
+            }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) tile[((j << (B - 4)) | g) * STRIDE + x] = v[j];
+        __syncthreads();
+        // ---- round B: stages RR2-1..0; pt = (o << RR2) | ji ----
+        const uint32_t phi = two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)lo << (B - RR2));
+        uint32_t* q = a.dst + base;
+#pragma unroll
+        for (uint32_t js = 0; js < NSUB; js++) {
+            const uint32_t o = js * GSPAN + g;
+            uint32_t e[SUB2];
+#pragma unroll
+            for (uint32_t ji = 0; ji < SUB2; ji++) e[ji] = tile[((o << RR2) | ji) * STRIDE + x];
+#pragma unroll
+            for (int u = RR2 - 1; u >= 0; u--) {
+#pragma unroll
+                for (uint32_t ji = 0; ji < SUB2; ji++) {
+                    if (ji & (1u << u)) continue;
+                    const uint32_t j1 = ji | (1u << u);
+                    const uint32_t w = twl[(1u << u) - 1u + (ji & ((1u << u) - 1u))];
+                    uint32_t s = e[ji], c = e[j1];
+                    e[ji] = bb::add(s, c);
+                    e[j1] = bb::mul(bb::sub(s, c), w);
+                }
+            }
+            // post-twiddle w^(rev_B(pt) * lo), rev_B((o << RR2) | ji) = (rev(ji) << (B-RR2)) | rev(o)
+            uint32_t c = two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)lo * rev_bits(o, B - RR2));
+            uint32_t pw[SUB2];
+            power_ladder<(int)SUB2>(c, phi, pw);
+            if (valid) {
+#pragma unroll
+                for (uint32_t ji = 0; ji < SUB2; ji++)
+                    q[(uint64_t)((o << RR2) | ji) * stride] = bb::mul(e[ji], pw[crev(ji, RR2)]);
+            }
+        }
+    }
+}
+
+
+// MODE 1: first DIT pass (s0 = 0): bit-reversal gather straight into the first round's registers; results go to
+//         contiguous groups (selected in bit-reversed order) — directly for W >= 32, through one more LDS
+//         exchange + column-wise copy for narrow power-of-two widths.
+// MODE 4: last DIF pass (s0 = 0) in place on contiguous groups: narrow widths are staged through LDS on both
+//         sides (column-wise copies keep HBM accesses contiguous), W >= 32 loads/stores directly.
+template <int B, int MODE>
+__global__ void __launch_bounds__(512) ntt_fast_group_kernel(PassArgs a) {
+    constexpr uint32_t RUN = 32, STRIDE = 33, NPTS = 1u << B, NTH = NPTS * 2, GSPAN = NPTS / 16;
+    constexpr int RR2 = B - 4;
+    constexpr uint32_t NSUB = 1u << (4 - RR2), SUB2 = 1u << RR2;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* tile = smem;
+    uint32_t* twl = smem + NPTS * STRIDE;
+    const uint32_t tid = threadIdx.x, x = tid & 31, g = tid >> 5;
+    for (uint32_t i = tid; i + 1 < NPTS; i += NTH) twl[i] = a.tile_tw[i];
+
+    const uint32_t bid = blockIdx.x;
+    const uint32_t gbits = a.n - B;
+    const bool narrow = a.W < RUN;
+    uint32_t h0, t, c;
+    bool valid;
+    if (narrow) {
+        h0 = bid * a.G;
+        t = x >> a.wshift;
+        c = x & (a.W - 1);
+        valid = t < a.G && ((uint64_t)h0 + t) < (1ull << gbits);
+    } else {
+        h0 = bid / a.n_inner;
+        t = 0;
+        c = (bid % a.n_inner) * RUN + x;
+        valid = c < a.W;
+    }
+    const uint64_t h = (uint64_t)h0 + t;
+    uint32_t v[16];
+
+    // column-wise cooperative copy between the LDS tile and the tile's contiguous groups (narrow widths)
+    auto colwise = [&](bool to_lds, const uint32_t* src, uint32_t* dst, bool rev_sel) {
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) {
+            const uint32_t idx = tid + j * NTH;
+            const uint32_t cc = idx & (a.W - 1), q = idx >> a.wshift;
+            const uint32_t pt = q & (NPTS - 1), tt = q >> B;
+            const uint64_t hh = (uint64_t)h0 + tt;
+            const bool ok = tt < a.G && hh < (1ull << gbits);
+            const uint64_t row = ((rev_sel ? (uint64_t)rev_bits((uint32_t)hh, gbits) : hh) << B) + pt;
+            const uint64_t word = (row << a.wshift) + cc;
+            if (to_lds) { if (ok) tile[pt * STRIDE + (tt << a.wshift) + cc] = src[word]; }
+            else { if (ok) { uint32_t val = tile[pt * STRIDE + (tt << a.wshift) + cc]; if (a.has_us) val = bb::mul(val, a.uscale); dst[word] = val; } }
+        }
+    };
+
+    if constexpr (MODE == 1) {
+        // rows (rev_B(16 g + j) << gbits) + h = h + (rev(g) << gbits) + rev4(j) * 2^(B-4+gbits)
+        const uint64_t stride1 = ((uint64_t)a.W << (B - 4)) << gbits;
+        const uint32_t* p = a.src + (h + ((uint64_t)rev_bits(g, B - 4) << gbits)) * a.W + c;
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) v[j] = valid ? p[(uint64_t)crev(j, 4) * stride1] : 0u;
+        __syncthreads();  // twl ready
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+#pragma unroll
+            for (uint32_t j0 = 0; j0 < 16; j0++) {
+                if (j0 & (1u << u)) continue;
+                const uint32_t j1 = j0 | (1u << u);
+                const uint32_t w = twl[(1u << u) - 1u + (j0 & ((1u << u) - 1u))];
+                uint32_t tt = bb::mul(v[j1], w), s = v[j0];
+                v[j0] = bb::add(s, tt);
+                v[j1] = bb::sub(s, tt);
+            }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) tile[(g * 16 + j) * STRIDE + x] = v[j];
+        __syncthreads();
+#pragma unroll
+        for (uint32_t js = 0; js < NSUB; js++) {
+            const uint32_t o = js * GSPAN + g;
+#pragma unroll
+            for (uint32_t ji = 0; ji < SUB2; ji++) v[js * SUB2 + ji] = tile[((ji << 4) | o) * STRIDE + x];
+#pragma unroll
+            for (int u = 0; u < RR2; u++) {
+                const uint32_t k = 4 + u;
+#pragma unroll
+                for (uint32_t ji = 0; ji < SUB2; ji++) {
+                    if (ji & (1u << u)) continue;
+                    const uint32_t j0 = js * SUB2 + ji, j1 = j0 | (1u << u);
+                    const uint32_t w = twl[(1u << k) - 1u + ((ji & ((1u << u) - 1u)) << 4) + o];
+                    uint32_t tt = bb::mul(v[j1], w), s = v[j0];
+                    v[j0] = bb::add(s, tt);
+                    v[j1] = bb::sub(s, tt);
+                }
+            }
+        }
+        if (narrow) {
+#pragma unroll
+            for (uint32_t js = 0; js < NSUB; js++)
+#pragma unroll
+                for (uint32_t ji = 0; ji < SUB2; ji++) tile[((ji << 4) | (js * GSPAN + g)) * STRIDE + x] = v[js * SUB2 + ji];
+            __syncthreads();
+            colwise(false, nullptr, a.dst, true);
+        } else if (valid) {
+            uint32_t* q = a.dst + ((uint64_t)rev_bits(h0, gbits) << B) * a.W + c;
+#pragma unroll
+            for (uint32_t js = 0; js < NSUB; js++)
+#pragma unroll
+                for (uint32_t ji = 0; ji < SUB2; ji++) {
+                    uint32_t val = v[js * SUB2 + ji];
+                    if (a.has_us) val = bb::mul(val, a.uscale);
+                    q[(uint64_t)((ji << 4) | (js * GSPAN + g)) * a.W] = val;
+                }
+        }
+    } else {
+        // ---- MODE 4 ----
+        if (narrow) {
+            colwise(true, a.src, nullptr, false);
+            __syncthreads();  // also covers twl
+#pragma unroll
+            for (uint32_t j = 0; j < 16; j++) v[j] = tile[((j << (B - 4)) | g) * STRIDE + x];
+        } else {
+            const uint32_t* p = a.src + ((uint64_t)h0 << B) * a.W + c;
+#pragma unroll
+            for (uint32_t j = 0; j < 16; j++) v[j] = valid ? p[(uint64_t)((j << (B - 4)) | g) * a.W] : 0u;
+            __syncthreads();  // twl ready
+        }
+#pragma unroll
+        for (int u = 3; u >= 0; u--) {
+            const uint32_t k = (B - 4) + u;
+#pragma unroll
+            for (uint32_t j0 = 0; j0 < 16; j0++) {
+                if (j0 & (1u << u)) continue;
+                const uint32_t j1 = j0 | (1u << u);
+                const uint32_t w = twl[(1u << k) - 1u + ((j0 & ((1u << u) - 1u)) << (B - 4)) + g];
+                uint32_t s = v[j0], d = v[j1];
+                v[j0] = bb::add(s, d);
+                v[j1] = bb::mul(bb::sub(s, d), w);
+            }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) tile[((j << (B - 4)) | g) * STRIDE + x] = v[j];
+        __syncthreads();
+#pragma unroll
+        for (uint32_t js = 0; js < NSUB; js++) {
+            const uint32_t o = js * GSPAN + g;
+            uint32_t e[SUB2];
+#pragma unroll
+            for (uint32_t ji = 0; ji < SUB2; ji++) e[ji] = tile[((o << RR2) | ji) * STRIDE + x];
+#pragma unroll
+            for (int u = RR2 - 1; u >= 0; u--) {
+#pragma unroll
+                for (uint32_t ji = 0; ji < SUB2; ji++) {
+                    if (ji & (1u << u)) continue;
+                    const uint32_t j1 = ji | (1u << u);
+                    const uint32_t w = twl[(1u << u) - 1u + (ji & ((1u << u) - 1u))];
+                    uint32_t s = e[ji], d = e[j1];
+                    e[ji] = bb::add(s, d);
+                    e[j1] = bb::mul(bb::sub(s, d), w);
+                }
+            }
+            if (narrow) {
+#pragma unroll
+                for (uint32_t ji = 0; ji < SUB2; ji++) tile[((o << RR2) | ji) * STRIDE + x] = e[ji];
+            } else if (valid) {
+                uint32_t* q = a.dst + ((uint64_t)h0 << B) * a.W + c;
+#pragma unroll
+                for (uint32_t ji = 0; ji < SUB2; ji++) q[(uint64_t)((o << RR2) | ji) * a.W] = e[ji];
+            }
+        }
+        if (narrow) {
+            __syncthreads();
+            colwise(false, nullptr, a.dst, false);
+        }
+    }
+}
+
+}  // namespace p3

@@ -51,6 +51,12 @@ struct PassArgs {
     uint32_t uscale;
     uint32_t sc_step;   // fast DIF kernel: shift^(rows between a lane's consecutive loads)
     uint32_t sc_base;   // the scale table's base (shift), host side only
+    // fused middle kernel only: forward-direction tables and shift^(16 * 2^s0)
+    const uint32_t* tile_tw2;
+    const uint32_t* tw2_lo;
+    const uint32_t* tw2_hi;
+    uint32_t tw2_T;
+    uint32_t sc_step16;
 };
 
 __device__ __forceinline__ uint32_t rev_bits(uint32_t v, uint32_t bits) {
@@ -688,6 +694,102 @@ int run_dif(Context& cx, hipStream_t stream, const uint32_t* src, uint64_t src_r
     return OK;
 }
 
+
+template <int BI, int A>
+int launch_fused_mid_t(hipStream_t stream, const PassArgs& a, uint32_t blocks) {
+    constexpr uint32_t NF = 1u << (BI + A);
+    size_t lds = (size_t)NF * 33 * 4 + (size_t)NF * 8;
+    hipLaunchKernelGGL((ntt_fused_mid_kernel<BI, A>), dim3(blocks), dim3(NF * 2), lds, stream, a);
+    P3_HIP(hipGetLastError());
+    return OK;
+}
+
+// coset LDE with the middle passes fused.  Returns 1 when the shape is not covered.
+int lde_fused(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* dst, uint32_t n, uint32_t added, uint32_t W,
+              uint32_t shift, bool bit_reversed_out) {
+    static int enabled = [] { const char* e = getenv("P3HIP_NTT_FUSED"); return e ? atoi(e) : 1; }();
+    if (!enabled || !bit_reversed_out || added < 1 || added > 2) return 1;
+    const uint32_t m = n + added;
+    // forward digits (lowest first) e1, e2, e3 with e3 = top; inverse digits e1, e2, e3 - added
+    std::vector<uint32_t> fd = split_digits(m);
+    if (fd.size() != 3) return 1;
+    uint32_t e1 = fd[0], e2 = fd[1], e3 = fd[2];
+    // put the largest digit on top so that e3 - added stays >= 5
+    if (e1 > e3) std::swap(e1, e3);
+    if (e2 > e3) std::swap(e2, e3);
+    if (e3 > 8 || e3 < added + 5 || e1 < 6 || e2 < 6 || e1 > 8 || e2 > 8) return 1;
+    const uint32_t bi = e3 - added, s0 = e1 + e2;
+    if (bi < 5 || (W < 32 && !is_pow2(W))) return 1;
+    if (bi < 6) return 1;  // kernels instantiated for BI in {6, 7}
+    const uint64_t N = 1ull << n;
+    size_t bytes = N * W * 4;
+    int rc = cx.ws[1].reserve(bytes);
+    if (rc) return rc;
+    uint32_t* coeffs = cx.ws[1].as<uint32_t>();
+    // inverse passes 1 and 2 (digits e1, e2) of the DIT plan
+    {
+        uint32_t digits[2] = {e1, e2};
+        uint32_t s = 0;
+        for (int i = 0; i < 2; i++) {
+            PassArgs a{};
+            a.W = W; a.n = n; a.b = digits[i]; a.s0 = s; a.dif = 0;
+            a.tile_tw = cx.tile_tw[1];
+            a.src_rows = N;
+            if (i == 0) { a.src = src; a.dst = coeffs; a.load_kind = SIDE_STRIDED; a.store_kind = SIDE_GROUP_REV; }
+            else { a.src = coeffs; a.dst = coeffs; a.load_kind = SIDE_INPLACE; a.store_kind = SIDE_INPLACE; }
+            rc = set_twiddle(cx, a, true);
+            if (rc) return rc;
+            rc = launch_pass(stream, a);
+            if (rc) return rc;
+            s += digits[i];
+        }
+    }
+    // fused middle: inverse top digit bi + scale + zero-extension + forward top digit e3
+    {
+        PassArgs a{};
+        a.W = W; a.n = n; a.b = bi; a.s0 = s0;
+        a.wshift = is_pow2(W) ? log2u(W) : 0xffffffffu;
+        a.src = coeffs; a.dst = dst;
+        a.tile_tw = cx.tile_tw[1];
+        a.tile_tw2 = cx.tile_tw[0];
+        TwoLevelTable ti, tf, sc;
+        if ((rc = cx.get_root_table(s0 + bi, true, &ti))) return rc;
+        if ((rc = cx.get_root_table(s0 + e3, false, &tf))) return rc;
+        uint32_t hinv = bb::inv(bb::to_monty((uint32_t)N));
+        if ((rc = cx.get_scale_table(shift, n, hinv, &sc))) return rc;
+        a.tw_lo = ti.lo; a.tw_hi = ti.hi; a.tw_T = ti.T;
+        a.tw2_lo = tf.lo; a.tw2_hi = tf.hi; a.tw2_T = tf.T;
+        a.sc_lo = sc.lo; a.sc_hi = sc.hi; a.sc_T = sc.T;
+        a.sc_step = bb::pow(shift, 1ull << s0);
+        a.sc_step16 = bb::pow(a.sc_step, 16);
+        uint64_t F = (uint64_t)W << s0;
+        uint32_t blocks = (uint32_t)((F + 31) / 32);
+        if (bi == 6 && added == 1) rc = launch_fused_mid_t<6, 1>(stream, a, blocks);
+        else if (bi == 7 && added == 1) rc = launch_fused_mid_t<7, 1>(stream, a, blocks);
+        else if (bi == 6 && added == 2) rc = launch_fused_mid_t<6, 2>(stream, a, blocks);
+        else return fail(ERR_INTERNAL, "lde_fused: unexpected digit shape");
+        if (rc) return rc;
+    }
+    // forward passes for digits e2 (s0 = e1) and e1 (s0 = 0), in place on dst
+    {
+        PassArgs a{};
+        a.W = W; a.n = m; a.b = e2; a.s0 = e1; a.dif = 1;
+        a.tile_tw = cx.tile_tw[0];
+        a.src = dst; a.dst = dst; a.src_rows = 1ull << m;
+        a.load_kind = SIDE_INPLACE; a.store_kind = SIDE_INPLACE;
+        if ((rc = set_twiddle(cx, a, false))) return rc;
+        if ((rc = launch_pass(stream, a))) return rc;
+        PassArgs b{};
+        b.W = W; b.n = m; b.b = e1; b.s0 = 0; b.dif = 1;
+        b.tile_tw = cx.tile_tw[0];
+        b.src = dst; b.dst = dst; b.src_rows = 1ull << m;
+        b.load_kind = SIDE_GROUP; b.store_kind = SIDE_GROUP;
+        if ((rc = set_twiddle(cx, b, false))) return rc;
+        if ((rc = launch_pass(stream, b))) return rc;
+    }
+    return OK;
+}
+
 }  // namespace
 
 int ntt_dft(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* dst, uint64_t height,
@@ -737,6 +839,11 @@ int ntt_coset_lde(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t
     if (m > bb::TWO_ADICITY) return fail(ERR_BAD_ARG, "LDE height exceeds BabyBear two-adicity");
     if (src == dst) return fail(ERR_BAD_ARG, "coset_lde: in-place not supported");
     size_t bytes = height * width * 4;
+    // Fused plan (three-pass shapes whose digits line up): inverse passes 1..2, fused middle, forward passes 2..3.
+    {
+        int rcf = lde_fused(cx, stream, src, dst, n, added_bits, width, shift, bit_reversed_out);
+        if (rcf != 1) return rcf;  // 0 = done, <0 = error, 1 = shape not covered: separate transforms below
+    }
     // 1. coefficients (natural order) into scratch: inverse DIT, 1/N folded into the scale table below
     int rc = cx.ws[1].reserve(bytes);
     if (rc) return rc;

@@ -353,4 +353,151 @@ __global__ void __launch_bounds__(512) ntt_fast_group_kernel(PassArgs a) {
     }
 }
 
+
+// Fused middle of the coset LDE: the LAST inverse (DIT) pass and the FIRST forward (DIF) pass share their row
+// stride 2^s0, so one workgroup can finish the inverse transform of its rows (BI stages), scale the
+// coefficients by shift^row / N, zero-extend to 2^(BI+A) rows and run the forward pass's top BF = BI + A
+// stages without the coefficients ever leaving the chip.  Saves one launch and one full write + read of
+// the coefficient matrix.  Inverse tile twiddles / tables: a.tile_tw, a.tw_*; forward: a.tile_tw2, a.tw2_*.
+template <int BI, int A>
+__global__ void __launch_bounds__(512) ntt_fused_mid_kernel(PassArgs a) {
+    constexpr int BF = BI + A;
+    constexpr uint32_t RUN = 32, STRIDE = 33, NI = 1u << BI, NF = 1u << BF, NTH = NF * 2;
+    constexpr int RI2 = BI - 4, RF2 = BF - 4;
+    constexpr uint32_t NSUBI = 1u << (4 - RI2), SUBI = 1u << RI2, GSPANI = NI / 16;
+    constexpr uint32_t NSUBF = 1u << (4 - RF2), SUBF = 1u << RF2, GSPANF = NF / 16;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* tile = smem;                    // NF rows
+    uint32_t* twl_i = smem + NF * STRIDE;     // inverse stage table (NI - 1 words used)
+    uint32_t* twl_f = twl_i + NF;             // forward stage table (NF - 1 words)
+    const uint32_t tid = threadIdx.x, x = tid & 31, g = tid >> 5;
+    for (uint32_t i = tid; i + 1 < NI; i += NTH) twl_i[i] = a.tile_tw[i];
+    for (uint32_t i = tid; i + 1 < NF; i += NTH) twl_f[i] = a.tile_tw2[i];
+
+    const uint64_t f = (uint64_t)blockIdx.x * RUN + x;  // the top digit spans the whole height: hi = 0
+    const bool valid = f < ((uint64_t)a.W << a.s0);
+    const uint32_t lo = a.wshift != 0xffffffffu ? (uint32_t)(f >> a.wshift) : (uint32_t)(f / a.W);
+    const uint64_t stride = (uint64_t)a.W << a.s0;
+    uint32_t v[16];
+
+    // ---------------- inverse: DIT over BI stages (threads with g < NI/16) ----------------
+    const bool inv_active = g < GSPANI;
+    if (inv_active) {
+        const uint32_t* p = a.src + f + (uint64_t)(g * 16) * stride;
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) v[j] = valid ? p[j * stride] : 0u;
+        uint32_t c = two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)lo * rev_bits(g, BI - 4));
+        uint32_t phi = two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)lo << (BI - 4));
+        uint32_t pw[16];
+        power_ladder<16>(c, phi, pw);
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) v[j] = bb::mul(v[j], pw[crev(j, 4)]);
+    }
+    __syncthreads();  // stage tables ready
+    if (inv_active) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+#pragma unroll
+            for (uint32_t j0 = 0; j0 < 16; j0++) {
+                if (j0 & (1u << u)) continue;
+                const uint32_t j1 = j0 | (1u << u);
+                const uint32_t w = twl_i[(1u << u) - 1u + (j0 & ((1u << u) - 1u))];
+                uint32_t t = bb::mul(v[j1], w), s = v[j0];
+                v[j0] = bb::add(s, t);
+                v[j1] = bb::sub(s, t);
+            }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) tile[(g * 16 + j) * STRIDE + x] = v[j];
+    }
+    __syncthreads();
+    if (inv_active) {
+        // coefficient row = pt * 2^s0 + lo; scale sc(row) = sc(lo) * (shift^(2^s0))^pt
+        const uint32_t c0 = valid ? two_level(a.sc_lo, a.sc_hi, a.sc_T, lo) : 0u;
+#pragma unroll
+        for (uint32_t js = 0; js < NSUBI; js++) {
+            const uint32_t o = js * GSPANI + g;
+#pragma unroll
+            for (uint32_t ji = 0; ji < SUBI; ji++) v[js * SUBI + ji] = tile[((ji << 4) | o) * STRIDE + x];
+#pragma unroll
+            for (int u = 0; u < RI2; u++) {
+                const uint32_t k = 4 + u;
+#pragma unroll
+                for (uint32_t ji = 0; ji < SUBI; ji++) {
+                    if (ji & (1u << u)) continue;
+                    const uint32_t j0 = js * SUBI + ji, j1 = j0 | (1u << u);
+                    const uint32_t w = twl_i[(1u << k) - 1u + ((ji & ((1u << u) - 1u)) << 4) + o];
+                    uint32_t t = bb::mul(v[j1], w), s = v[j0];
+                    v[j0] = bb::add(s, t);
+                    v[j1] = bb::sub(s, t);
+                }
+            }
+            // pt = (ji << 4) | o: scale = c0 * step^o * (step^16)^ji, step = shift^(2^s0)
+            uint32_t pw[SUBI];
+            power_ladder<(int)SUBI>(bb::mul(c0, bb::pow(a.sc_step, o)), a.sc_step16, pw);
+#pragma unroll
+            for (uint32_t ji = 0; ji < SUBI; ji++) v[js * SUBI + ji] = bb::mul(v[js * SUBI + ji], pw[ji]);
+        }
+    }
+    __syncthreads();  // every round-2 read of the tile is done before it is overwritten
+    if (inv_active) {
+#pragma unroll
+        for (uint32_t js = 0; js < NSUBI; js++)
+#pragma unroll
+            for (uint32_t ji = 0; ji < SUBI; ji++) tile[((ji << 4) | (js * GSPANI + g)) * STRIDE + x] = v[js * SUBI + ji];
+    }
+    __syncthreads();
+    // ---------------- forward: DIF over BF stages, rows >= NI are zero ----------------
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) {
+        const uint32_t pt = (j << (BF - 4)) | g;
+        v[j] = pt < NI ? tile[pt * STRIDE + x] : 0u;
+    }
+    __syncthreads();  // all coefficient reads done before round A overwrites the tile
+#pragma unroll
+    for (int u = 3; u >= 0; u--) {
+        const uint32_t k = (BF - 4) + u;
+#pragma unroll
+        for (uint32_t j0 = 0; j0 < 16; j0++) {
+            if (j0 & (1u << u)) continue;
+            const uint32_t j1 = j0 | (1u << u);
+            const uint32_t w = twl_f[(1u << k) - 1u + ((j0 & ((1u << u) - 1u)) << (BF - 4)) + g];
+            uint32_t s = v[j0], d = v[j1];
+            v[j0] = bb::add(s, d);
+            v[j1] = bb::mul(bb::sub(s, d), w);
+        }
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) tile[((j << (BF - 4)) | g) * STRIDE + x] = v[j];
+    __syncthreads();
+    const uint32_t phi2 = two_level(a.tw2_lo, a.tw2_hi, a.tw2_T, (uint64_t)lo << (BF - RF2));
+    uint32_t* q = a.dst + f;
+#pragma unroll
+    for (uint32_t js = 0; js < NSUBF; js++) {
+        const uint32_t o = js * GSPANF + g;
+        uint32_t e[SUBF];
+#pragma unroll
+        for (uint32_t ji = 0; ji < SUBF; ji++) e[ji] = tile[((o << RF2) | ji) * STRIDE + x];
+#pragma unroll
+        for (int u = RF2 - 1; u >= 0; u--) {
+#pragma unroll
+            for (uint32_t ji = 0; ji < SUBF; ji++) {
+                if (ji & (1u << u)) continue;
+                const uint32_t j1 = ji | (1u << u);
+                const uint32_t w = twl_f[(1u << u) - 1u + (ji & ((1u << u) - 1u))];
+                uint32_t s = e[ji], d = e[j1];
+                e[ji] = bb::add(s, d);
+                e[j1] = bb::mul(bb::sub(s, d), w);
+            }
+        }
+        uint32_t c = two_level(a.tw2_lo, a.tw2_hi, a.tw2_T, (uint64_t)lo * rev_bits(o, BF - RF2));
+        uint32_t pw[SUBF];
+        power_ladder<(int)SUBF>(c, phi2, pw);
+        if (valid) {
+#pragma unroll
+            for (uint32_t ji = 0; ji < SUBF; ji++) q[(uint64_t)((o << RF2) | ji) * stride] = bb::mul(e[ji], pw[crev(ji, RF2)]);
+        }
+    }
+}
+
 }  // namespace p3

@@ -143,6 +143,11 @@ int p3hip_fib_prover_prove(p3hip_fib_prover_t *prover, uint64_t a, uint64_t b, c
  * accumulated over *proofs proofs */
 int p3hip_fib_prover_stage_times(p3hip_fib_prover_t *prover, double out_ms[6], uint64_t *proofs, int reset);
 void p3hip_fib_prover_destroy(p3hip_fib_prover_t *prover);
+/* verify(&config, &FibonacciAir{}, &proof, &pis) (native/src/fib_air.rs:71-72) with pis = [a, b, x]: host-side, a few
+ * thousand permutations.  Returns 0 to accept, a positive code naming the failed check otherwise (message via
+ * p3hip_take_last_error, e.g. "fib_air verification failed: OodEvaluationMismatch"). */
+int p3hip_verify_fib_air(const uint8_t *proof, size_t len, uint64_t a, uint64_t b, uint64_t x, unsigned log_n,
+                         const p3hip_fri_params_t *params);
 
 #ifdef __cplusplus
 }

@@ -170,4 +170,24 @@ class FibAirProver {  // prove(&config, &FibonacciAir{}, generate_trace_rows(a, 
     p3hip_fib_prover_t* h_ = nullptr;
 };
 
+// generate_trace_rows' last right value = the public value x (fib_air.rs:57,68)
+inline uint64_t fib_public_x(uint64_t a, uint64_t b, uint64_t n) {
+    uint64_t l = a % P, r = b % P;
+    for (uint64_t i = 1; i < n; i++) { uint64_t t = (l + r) % P; l = r; r = t; }
+    return r;
+}
+// verify(&config, &FibonacciAir{}, &proof, &pis) (fib_air.rs:71-72); throws Error("fib_air verification failed: ...")
+inline void verify_fib_air(const std::vector<uint8_t>& proof, uint64_t a, uint64_t b, uint64_t x, unsigned log_n,
+                           FriParameters fp = FriParameters()) {
+    p3hip_fri_params_t c{fp.log_blowup, fp.log_final_poly_len, fp.num_queries, fp.proof_of_work_bits};
+    check(p3hip_verify_fib_air(proof.data(), proof.size(), a, b, x, log_n, &c));
+}
+// run_fib_air_zk (fib_air.rs:27-75) on the hip backend, Poseidon2 configuration: "fib_air ok (n=8, x=21)"
+inline std::string run_fib_air(unsigned log_n = 3, uint64_t a = 0, uint64_t b = 1, FriParameters fp = FriParameters()) {
+    uint64_t n = 1ull << log_n, x = fib_public_x(a, b, n);
+    FibAirProver prover(log_n, fp);
+    verify_fib_air(prover.prove(a, b), a, b, x, log_n, fp);
+    return "fib_air ok (n=" + std::to_string(n) + ", x=" + std::to_string(x) + ")";
+}
+
 }  // namespace p3hip

@@ -357,12 +357,14 @@ int p3o_verify_fib_air(const uint8_t *proof, size_t len, uint64_t a, uint64_t b,
         size_t index = chal_sample_bits(&ch, log_big);
         uint32_t trow[2], qrow[4];
         size_t dims_h[1] = {(size_t)1 << log_big}, dims_w[1];
-        get_u32(&rd);
-        get_u32(&rd); if (get_u32(&rd) != 2) { rc = 12; break; } get_words(&rd, trow, 2);
+        if (get_u32(&rd) != 2) { rc = 12; break; }
+        if (get_u32(&rd) != 1 || get_u32(&rd) != 2) { rc = 12; break; }
+        get_words(&rd, trow, 2);
         if (get_u32(&rd) != log_big) { rc = 12; break; } get_words(&rd, path, 8 * (size_t)log_big);
         dims_w[0] = 2;
         if (p3o_mmcs_verify_batch(root_t, dims_h, dims_w, 1, index, trow, path, log_big)) { rc = 13; break; }
-        get_u32(&rd); if (get_u32(&rd) != 4) { rc = 12; break; } get_words(&rd, qrow, 4);
+        if (get_u32(&rd) != 1 || get_u32(&rd) != 4) { rc = 12; break; }
+        get_words(&rd, qrow, 4);
         if (get_u32(&rd) != log_big) { rc = 12; break; } get_words(&rd, path, 8 * (size_t)log_big);
         dims_w[0] = 4;
         if (p3o_mmcs_verify_batch(root_q, dims_h, dims_w, 1, index, qrow, path, log_big)) { rc = 13; break; }

@@ -367,4 +367,16 @@ int p3hip_fib_prover_stage_times(p3hip_fib_prover_t* prover, double out_ms[6], u
 
 void p3hip_fib_prover_destroy(p3hip_fib_prover_t* prover) { delete prover; }
 
+int p3hip_verify_fib_air(const uint8_t* proof, size_t len, uint64_t a, uint64_t b, uint64_t x, unsigned log_n,
+                         const p3hip_fri_params_t* params) {
+    return guarded([&]() -> int {
+        if (!proof || !params) return fail(ERR_BAD_ARG, "verify_fib_air: null argument");
+        FriParams fp{params->log_blowup, params->log_final_poly_len, params->num_queries, params->proof_of_work_bits};
+        std::string why;
+        int rc = verify_fib_air(proof, len, a, b, x, log_n, fp, &why);
+        if (rc != 0) set_error("fib_air verification failed: " + why);
+        return rc;
+    });
+}
+
 }  // extern "C"

@@ -196,6 +196,27 @@ __global__ void poseidon2_permute_kernel(uint32_t* states, uint64_t n) {
     for (int k = 0; k < 4; k++) q[k] = make_uint4(s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]);
 }
 
+__global__ void __launch_bounds__(256) poseidon2_permute_x2_kernel(uint32_t* states, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t half = (n + 1) / 2;
+    if (i >= half) return;
+    uint32_t s[16], t[16];
+    uint4* q = reinterpret_cast<uint4*>(states + i * 16);
+    uint64_t i2 = i + half < n ? i + half : i;
+    uint4* q2 = reinterpret_cast<uint4*>(states + i2 * 16);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { uint4 v = q[k]; s[4 * k] = v.x; s[4 * k + 1] = v.y; s[4 * k + 2] = v.z; s[4 * k + 3] = v.w; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { uint4 v = q2[k]; t[4 * k] = v.x; t[4 * k + 1] = v.y; t[4 * k + 2] = v.z; t[4 * k + 3] = v.w; }
+    p2::permute2(s, t);
+#pragma unroll
+    for (int k = 0; k < 4; k++) q[k] = make_uint4(s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]);
+    if (i2 != i) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) q2[k] = make_uint4(t[4 * k], t[4 * k + 1], t[4 * k + 2], t[4 * k + 3]);
+    }
+}
+
 __global__ void poseidon2_permute_f64_kernel(uint32_t* states, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -214,6 +235,13 @@ __global__ void poseidon2_permute_f64_kernel(uint32_t* states, uint64_t n) {
 
 int poseidon2_permute_states(hipStream_t stream, uint32_t* d_states, uint64_t n) {
     static int use_f64 = [] { const char* e = getenv("P3HIP_P2_F64"); return e ? atoi(e) : 0; }();
+    static int use_x2 = [] { const char* e = getenv("P3HIP_P2_X2"); return e ? atoi(e) : 0; }();
+    if (n && use_x2) {
+        uint64_t half = (n + 1) / 2;
+        hipLaunchKernelGGL(poseidon2_permute_x2_kernel, dim3((uint32_t)((half + 255) / 256)), dim3(256), 0, stream, d_states, n);
+        P3_HIP(hipGetLastError());
+        return OK;
+    }
     if (n && use_f64) {
         hipLaunchKernelGGL(poseidon2_permute_f64_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_states, n);
         P3_HIP(hipGetLastError());

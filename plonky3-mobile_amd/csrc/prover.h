@@ -1,6 +1,7 @@
 // fib_air prover object: one instance owns its HBM arena and stream, reusable across proofs.
 #pragma once
 #include <chrono>
+#include <string>
 #include <vector>
 
 #include "common.h"
@@ -32,5 +33,9 @@ class FibProver {
     struct Impl;
     Impl* im;
 };
+
+// verifier.hip: p3_uni_stark::verify for FibonacciAir on the host (0 = accept, else the failed check's code)
+int verify_fib_air(const uint8_t* proof, size_t len, uint64_t a_pub, uint64_t b_pub, uint64_t x_pub, uint32_t log_n,
+                   const FriParams& fp, std::string* why);
 
 }  // namespace p3

@@ -176,3 +176,34 @@ def run_dft_benchmark(cases=None, warmup=1, repeats=10, e2e_batch_size=4, cpu_df
         lines.append(line)
         rows.append(row)
     return "\n".join(lines), rows
+
+
+def fib_public_x(a, b, n):
+    """Last row's right value (the public value x, fib_air.rs:57,68), canonical integer."""
+    l, r = a % _P, b % _P
+    for _ in range(n - 1):
+        l, r = r, (l + r) % _P
+    return r
+
+
+def verify_fib_air(proof, a, b, x, log_n, params=None):
+    """verify(&config, &FibonacciAir{}, &proof, &[a, b, x]) (fib_air.rs:71-72), host side.  Raises
+    P3HipError("fib_air verification failed: <check>") on rejection, like the reference's map_err."""
+    params = params or FriParameters()
+    buf = (C.c_uint8 * len(proof)).from_buffer_copy(proof)
+    _lib.check(_lib.lib().p3hip_verify_fib_air(buf, len(proof), a, b, x, log_n, C.cast(params._c(), C.c_void_p)))
+
+
+def run_fib_air(log_n=3, a=0, b=1, params=None):
+    """run_fib_air_zk (fib_air.rs:27-75) on the hip backend with the Poseidon2 configuration: prove, verify,
+    report.  Default n = 8, x = 21 as in the reference (fib_air.rs:56-57)."""
+    params = params or FriParameters()
+    n = 1 << log_n
+    x = fib_public_x(a, b, n)
+    prover = FibAirProver(log_n, params=params)
+    try:
+        proof = prover.prove(a, b)
+    finally:
+        prover.close()
+    verify_fib_air(proof, a, b, x, log_n, params)
+    return "fib_air ok (n=%d, x=%d)" % (n, x)

@@ -113,3 +113,9 @@ def test_dft_benchmark_harness(p3, oracle):
     assert text.startswith("dft benchmark (repeats=3, warmup=1, stats=avg/median/p95)")
     assert len(rows) == 3 and all(r["hip_kernel"][0] > 0 for r in rows)
     assert p3.percentile_ms([3.0, 1.0, 2.0, 4.0], 0.95) == 4.0 and p3.percentile_ms([], 0.5) == 0.0
+
+
+def test_run_fib_air_mirrors_reference_report(p3):
+    # run_fib_air_zk returns "fib_air zk ok (n=8, x=21)" (fib_air.rs:74); ours proves + verifies on the hip backend
+    assert p3.run_fib_air(params=p3.FriParameters(1, 0, 10, 4)) == "fib_air ok (n=8, x=21)"
+    assert p3.run_fib_air(log_n=12).startswith("fib_air ok (n=4096, x=")

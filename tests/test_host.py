@@ -51,3 +51,25 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cuh", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.replace("test oracle", ""), os.path.join(dirpath, f)
+
+
+def test_product_verifier_accepts_oracle_proofs_and_rejects_tampering(p3, oracle):
+    """p3hip_verify_fib_air is host code (no GPU needed): cross-check it against the oracle's prover, and the
+    oracle's verifier against the same inputs."""
+    import numpy as np
+    for log_n, t in [(3, (1, 0, 10, 4)), (7, (2, 2, 6, 5)), (10, (1, 0, 100, 16))]:
+        ofp, gfp = oracle.FriParams(*t), p3.FriParameters(*t)
+        proof = oracle.prove_fib_air(0, 1, log_n, ofp)
+        x = p3.fib_public_x(0, 1, 1 << log_n)
+        assert x == oracle.fib_public_x(0, 1, 1 << log_n)
+        p3.verify_fib_air(proof, 0, 1, x, log_n, gfp)  # accepts
+        with pytest.raises(p3.P3HipError, match="OodEvaluationMismatch"):
+            p3.verify_fib_air(proof, 0, 1, x + 1, log_n, gfp)
+        words = np.frombuffer(proof, dtype=np.uint32)
+        rng = np.random.default_rng(log_n)
+        for pos in rng.choice(len(words), size=25, replace=False):
+            bad = words.copy()
+            bad[pos] = (int(bad[pos]) + 1) % 0x78000001
+            with pytest.raises(p3.P3HipError):
+                p3.verify_fib_air(bad.tobytes(), 0, 1, x, log_n, gfp)
+            assert oracle.verify_fib_air(bad.tobytes(), 0, 1, x, log_n, ofp) != 0

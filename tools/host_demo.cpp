@@ -52,6 +52,11 @@ int main(int argc, char** argv) {
         auto again = prover.prove(0, 1);
         if (proof != again || proof.size() < 1000) { std::printf("FAIL prove\n"); return 6; }
         std::printf("fib_air ok: proof %zu bytes, first word %08x\n", proof.size(), *(const uint32_t*)proof.data());
+        std::string rep = run_fib_air();  // the reference's instance: n = 8, x = 21 (fib_air.rs:56-57)
+        std::printf("%s\n", rep.c_str());
+        if (rep != "fib_air ok (n=8, x=21)") { std::printf("FAIL run_fib_air\n"); return 7; }
+        try { verify_fib_air(proof, 0, 1, 5, argc > 1 ? std::atoi(argv[1]) : 12); std::printf("FAIL verify accepted a wrong x\n"); return 8; }
+        catch (const Error& e) { std::printf("expected error: %s\n", e.what()); }
         std::printf("OK\n");
         return 0;
     } catch (const Error& e) {

@@ -165,10 +165,18 @@ def main():
                      "frac": roof["gbps"] / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "coset_lde_batch (ntt_pass_kernel launches)", "algorithmic_bytes": roof["bytes"],
                      "avg_us": roof["avg_us"], "batched_gbps": roof.get("batched_gbps")},
+        # The kernel that dominates a proof BY TIME is Poseidon2 (12.6 M permutations per 2^20 proof, ~80 % of the GPU
+        # time) and it is integer-VALU-bound, which the contract's hbm|mfma roofline cannot express: reported here
+        # against the issue ceiling derived from the measured per-instruction rates.
+        "valu_roofline": {"kernel": "Poseidon2 leaf/compress (one state per lane)", "achieved": job.poseidon2_rate() / 1e9,
+                          "peak": 6.4, "unit": "Gperm/s", "instructions_per_permutation": 7229,
+                          "peak_basis": "3.2k full-rate (2.45 cyc) + 4.0k half-rate (4.2 cyc) wave-instructions per "
+                                        "permutation on 1024 SIMDs at 2.4 GHz (profiles/r01_microbench2_valu_issue_rates.txt)"},
         "stages_ms": job.stage_breakdown(),
         "collectives": coll_state["mode"],
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["valu_roofline"]["frac"] = out["valu_roofline"]["achieved"] / out["valu_roofline"]["peak"]
         out["cpu_baseline"] = cpu_baseline(args.log_height, args.log_blowup, job)
     job.close()
     if rank == 0:

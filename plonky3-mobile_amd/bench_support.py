@@ -162,6 +162,15 @@ class FibAirJob:
         res["batched_gbps"] = 64 * nbytes / (wms * 1e-3) / 1e9
         return res
 
+    def poseidon2_rate(self, reps=5):
+        """Poseidon2 permutations/s of the one-state-per-lane kernel (the dominant kernel of a proof by time),
+        HIP events on the launch stream, 2^22 random states in HBM."""
+        n = 1 << 22
+        st = torch.randint(0, 0x78000001, (n, 16), dtype=torch.int32, device="cuda")
+        L = _lib.lib()
+        ms = self._time(lambda: _lib.check(L.p3hip_poseidon2_permute_dev(C.c_void_p(st.data_ptr()), n, _stream_ptr())), reps)
+        return n / (ms * 1e-3)
+
     def stage_breakdown(self):
         trace = generate_trace_rows(0, 1, self.n)
         t_trace = self._time(lambda: generate_trace_rows(0, 1, self.n), 5)

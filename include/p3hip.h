@@ -149,6 +149,18 @@ void p3hip_fib_prover_destroy(p3hip_fib_prover_t *prover);
 int p3hip_verify_fib_air(const uint8_t *proof, size_t len, uint64_t a, uint64_t b, uint64_t x, unsigned log_n,
                          const p3hip_fri_params_t *params);
 
+/* ---- batches of independent proofs (BASELINE configs[3]; SURVEY.md §8e: instance i is self-contained) ------
+ * A pool of n_provers provers, each on its own host thread (thread-local context, as the reference's runtime,
+ * backend_vulkan.rs:100-102) and its own stream, so the transcript round trips of one proof hide behind the
+ * kernels of the others.  p3hip_fib_batch_prove proves instances (a[i], b[i]) and returns pointers to the proof
+ * bytes, valid until the next call on the same batch. */
+typedef struct p3hip_fib_batch p3hip_fib_batch_t;
+int p3hip_fib_batch_create(unsigned log_n, const p3hip_fri_params_t *params, unsigned n_provers,
+                           p3hip_fib_batch_t **out);
+int p3hip_fib_batch_prove(p3hip_fib_batch_t *batch, size_t n, const uint64_t *a, const uint64_t *b,
+                          const uint8_t **proofs_out, size_t *lens_out);
+void p3hip_fib_batch_destroy(p3hip_fib_batch_t *batch);
+
 #ifdef __cplusplus
 }
 #endif

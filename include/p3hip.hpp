@@ -170,6 +170,31 @@ class FibAirProver {  // prove(&config, &FibonacciAir{}, generate_trace_rows(a, 
     p3hip_fib_prover_t* h_ = nullptr;
 };
 
+// A pool of provers (one host thread + stream each) for batches of independent instances (BASELINE configs[3]).
+class FibAirBatchProver {
+  public:
+    FibAirBatchProver(unsigned log_n, unsigned n_provers = 8, FriParameters fp = FriParameters()) {
+        p3hip_fri_params_t c{fp.log_blowup, fp.log_final_poly_len, fp.num_queries, fp.proof_of_work_bits};
+        check(p3hip_fib_batch_create(log_n, &c, n_provers, &h_));
+    }
+    FibAirBatchProver(const FibAirBatchProver&) = delete;
+    ~FibAirBatchProver() { if (h_) p3hip_fib_batch_destroy(h_); }
+    std::vector<std::vector<uint8_t>> prove(const std::vector<std::pair<uint64_t, uint64_t>>& instances) {
+        size_t n = instances.size();
+        std::vector<uint64_t> a(n), b(n);
+        for (size_t i = 0; i < n; i++) { a[i] = instances[i].first; b[i] = instances[i].second; }
+        std::vector<const uint8_t*> ptrs(n);
+        std::vector<size_t> lens(n);
+        check(p3hip_fib_batch_prove(h_, n, a.data(), b.data(), ptrs.data(), lens.data()));
+        std::vector<std::vector<uint8_t>> out(n);
+        for (size_t i = 0; i < n; i++) out[i].assign(ptrs[i], ptrs[i] + lens[i]);
+        return out;
+    }
+
+  private:
+    p3hip_fib_batch_t* h_ = nullptr;
+};
+
 // generate_trace_rows' last right value = the public value x (fib_air.rs:57,68)
 inline uint64_t fib_public_x(uint64_t a, uint64_t b, uint64_t n) {
     uint64_t l = a % P, r = b % P;

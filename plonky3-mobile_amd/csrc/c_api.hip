@@ -4,6 +4,9 @@
 #include "../../include/p3hip.h"
 
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cctype>
 #include <cstdio>
 #include <cstring>
@@ -377,6 +380,115 @@ int p3hip_verify_fib_air(const uint8_t* proof, size_t len, uint64_t a, uint64_t 
         if (rc != 0) set_error("fib_air verification failed: " + why);
         return rc;
     });
+}
+
+}  // extern "C"
+
+// ---- batches of independent proofs (BASELINE configs[3]): a pool of provers, one host thread + stream each ----
+struct p3hip_fib_batch {
+    unsigned log_n = 0;
+    FriParams fp{};
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    // current job
+    uint64_t generation = 0;
+    bool stop = false;
+    size_t n = 0, next = 0, done = 0, ready = 0;
+    const uint64_t* a = nullptr;
+    const uint64_t* b = nullptr;
+    std::vector<std::vector<uint8_t>> proofs;
+    int first_error = 0;
+    std::string error_text;
+
+    void worker_main() {
+        FibProver prover;
+        hipStream_t st = nullptr;
+        int rc = get_context_status();
+        if (rc == OK && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) rc = fail(ERR_HIP, "hipStreamCreateWithFlags failed");
+        if (rc == OK) rc = prover.init(log_n, fp, st, true);
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            if (rc != OK && first_error == 0) { first_error = rc; std::string t; take_error(&t); error_text = t; }
+            ready++;
+            cv_done.notify_all();
+        }
+        uint64_t seen = 0;
+        for (;;) {
+            size_t i;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || (generation != seen && next < n) ; });
+                if (stop) return;
+                if (next >= n) { seen = generation; continue; }
+                i = next++;
+            }
+            int prc = rc;
+            if (prc == OK) prc = prover.prove(a[i], b[i], &proofs[i]);
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                if (prc != OK && first_error == 0) { first_error = prc; std::string t; take_error(&t); error_text = t; }
+                done++;
+                if (next >= n) seen = generation;
+                if (done == n) cv_done.notify_all();
+            }
+        }
+    }
+    static int get_context_status() { Context* cx; return get_context(&cx); }
+};
+
+extern "C" {
+
+int p3hip_fib_batch_create(unsigned log_n, const p3hip_fri_params_t* params, unsigned n_provers, p3hip_fib_batch_t** out) {
+    return guarded([&]() -> int {
+        if (!params || !out || n_provers == 0 || n_provers > 64) return fail(ERR_BAD_ARG, "fib_batch_create: bad argument");
+        std::unique_ptr<p3hip_fib_batch> bt(new p3hip_fib_batch());
+        bt->log_n = log_n;
+        bt->fp = FriParams{params->log_blowup, params->log_final_poly_len, params->num_queries, params->proof_of_work_bits};
+        for (unsigned t = 0; t < n_provers; t++) bt->workers.emplace_back([p = bt.get()] { p->worker_main(); });
+        {
+            std::unique_lock<std::mutex> lk(bt->mu);
+            bt->cv_done.wait(lk, [&] { return bt->ready == n_provers; });
+        }
+        if (bt->first_error) {
+            int rc = bt->first_error;
+            std::string text = bt->error_text;
+            p3hip_fib_batch_destroy(bt.release());
+            return fail(rc, text);
+        }
+        *out = bt.release();
+        return OK;
+    });
+}
+
+int p3hip_fib_batch_prove(p3hip_fib_batch_t* bt, size_t n, const uint64_t* a, const uint64_t* b, const uint8_t** proofs_out,
+                          size_t* lens_out) {
+    return guarded([&]() -> int {
+        if (!bt || (n && (!a || !b || !proofs_out || !lens_out))) return fail(ERR_BAD_ARG, "fib_batch_prove: null argument");
+        if (!n) return OK;
+        {
+            std::unique_lock<std::mutex> lk(bt->mu);
+            if (bt->proofs.size() < n) bt->proofs.resize(n);
+            bt->n = n; bt->next = 0; bt->done = 0; bt->a = a; bt->b = b; bt->first_error = 0;
+            bt->generation++;
+            bt->cv_work.notify_all();
+            bt->cv_done.wait(lk, [&] { return bt->done == n; });
+            if (bt->first_error) return fail(bt->first_error, bt->error_text);
+        }
+        for (size_t i = 0; i < n; i++) { proofs_out[i] = bt->proofs[i].data(); lens_out[i] = bt->proofs[i].size(); }
+        return OK;
+    });
+}
+
+void p3hip_fib_batch_destroy(p3hip_fib_batch_t* bt) {
+    if (!bt) return;
+    {
+        std::unique_lock<std::mutex> lk(bt->mu);
+        bt->stop = true;
+        bt->cv_work.notify_all();
+    }
+    for (auto& t : bt->workers) t.join();
+    delete bt;
 }
 
 }  // extern "C"

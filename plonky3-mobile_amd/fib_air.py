@@ -207,3 +207,34 @@ def run_fib_air(log_n=3, a=0, b=1, params=None):
         prover.close()
     verify_fib_air(proof, a, b, x, log_n, params)
     return "fib_air ok (n=%d, x=%d)" % (n, x)
+
+
+class FibAirBatchProver:
+    """A pool of provers inside libp3hip (one host thread + stream + HBM arena each) proving batches of
+    independent instances — BASELINE configs[3] on one GPU; across GPUs see batch.py."""
+
+    def __init__(self, log_n, n_provers=8, params=None):
+        self.params = params or FriParameters()
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().p3hip_fib_batch_create(log_n, C.cast(self.params._c(), C.c_void_p), n_provers, C.byref(self._h)))
+
+    def prove(self, instances):
+        """instances: list of (a, b).  Returns the list of proof bytes in the same order."""
+        n = len(instances)
+        a = (C.c_uint64 * n)(*[i[0] for i in instances])
+        b = (C.c_uint64 * n)(*[i[1] for i in instances])
+        ptrs = (C.POINTER(C.c_uint8) * n)()
+        lens = (C.c_size_t * n)()
+        _lib.check(_lib.lib().p3hip_fib_batch_prove(self._h, n, a, b, ptrs, lens))
+        return [C.string_at(ptrs[i], lens[i]) for i in range(n)]
+
+    def close(self):
+        if self._h:
+            _lib.lib().p3hip_fib_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

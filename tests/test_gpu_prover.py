@@ -119,3 +119,19 @@ def test_run_fib_air_mirrors_reference_report(p3):
     # run_fib_air_zk returns "fib_air zk ok (n=8, x=21)" (fib_air.rs:74); ours proves + verifies on the hip backend
     assert p3.run_fib_air(params=p3.FriParameters(1, 0, 10, 4)) == "fib_air ok (n=8, x=21)"
     assert p3.run_fib_air(log_n=12).startswith("fib_air ok (n=4096, x=")
+
+
+def test_batch_prover_pool(p3, oracle):
+    """p3hip_fib_batch_*: a pool of provers inside the library; results in instance order, repeatable."""
+    gfp, ofp = _fp(p3, oracle, 1, 0, 16, 6)
+    pool = p3.FibAirBatchProver(10, n_provers=4, params=gfp)
+    inst = [(i, 2 * i + 1) for i in range(11)]
+    proofs = pool.prove(inst)
+    assert [len(p) > 1000 for p in proofs] == [True] * 11
+    for (a, b), pf in zip(inst[:4], proofs[:4]):
+        assert pf == oracle.prove_fib_air(a, b, 10, ofp)
+    for (a, b), pf in zip(inst, proofs):
+        p3.verify_fib_air(pf, a, b, p3.fib_public_x(a, b, 1 << 10), 10, gfp)
+    assert pool.prove(inst[:3]) == proofs[:3]
+    assert pool.prove([]) == []
+    pool.close()

@@ -57,6 +57,18 @@ int main(int argc, char** argv) {
         if (rep != "fib_air ok (n=8, x=21)") { std::printf("FAIL run_fib_air\n"); return 7; }
         try { verify_fib_air(proof, 0, 1, 5, argc > 1 ? std::atoi(argv[1]) : 12); std::printf("FAIL verify accepted a wrong x\n"); return 8; }
         catch (const Error& e) { std::printf("expected error: %s\n", e.what()); }
+        {   // batch of independent proofs through the library's prover pool
+            unsigned ln = argc > 1 ? std::atoi(argv[1]) : 12;
+            FibAirBatchProver pool(ln, 4);
+            std::vector<std::pair<uint64_t, uint64_t>> inst;
+            for (uint64_t i = 0; i < 16; i++) inst.push_back({i, i + 1});
+            auto t0 = std::chrono::steady_clock::now();
+            auto proofs = pool.prove(inst);
+            double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            for (size_t i = 0; i < inst.size(); i++) verify_fib_air(proofs[i], inst[i].first, inst[i].second, fib_public_x(inst[i].first, inst[i].second, 1ull << ln), ln);
+            if (proofs[0] != proof) { std::printf("FAIL batch proof 0 differs\n"); return 9; }
+            std::printf("batch of %zu proofs (2^%u rows): %.1f ms, all verified\n", inst.size(), ln, ms);
+        }
         std::printf("OK\n");
         return 0;
     } catch (const Error& e) {

@@ -135,3 +135,13 @@ def test_batch_prover_pool(p3, oracle):
     assert pool.prove(inst[:3]) == proofs[:3]
     assert pool.prove([]) == []
     pool.close()
+
+
+def test_reference_fri_parameters_n8(p3, oracle):
+    """The reference's own call: n = 8, x = 21, create_test_fri_params(challenge_mmcs, 2) (fib_air.rs:56-62) =
+    log_blowup 2, log_final_poly_len 2, 2 queries, 1 proof-of-work bit [UPSTREAM-RECALL for the values]."""
+    gfp, ofp = _fp(p3, oracle, 2, 2, 2, 1)
+    assert p3.run_fib_air(log_n=3, params=gfp) == "fib_air ok (n=8, x=21)"
+    proof = p3.FibAirProver(3, params=gfp).prove(0, 1)
+    assert proof == oracle.prove_fib_air(0, 1, 3, ofp)
+    assert oracle.verify_fib_air(proof, 0, 1, 21, 3, ofp) == 0

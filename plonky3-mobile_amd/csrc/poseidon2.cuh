@@ -15,6 +15,10 @@ namespace p2 {
 template <int K>
 BB_HD uint32_t div2k(uint32_t x) {
     static_assert(K >= 1 && K <= 27, "");
+    if constexpr (K == 1) {
+        // x/2 = (x >> 1) + (x odd ? (P+1)/2 : 0): four ops
+        return (x >> 1) + ((0u - (x & 1u)) & ((bb::P + 1u) >> 1));
+    }
     uint32_t m = (0u - x) & ((1u << K) - 1u);
     return ((x + m) >> K) + ((m * 15u) << (27 - K));
 }

@@ -600,8 +600,8 @@ int FibProver::prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof) {
         hp[16] = 0xffffffffu;
         P3_HIP(hipMemcpyAsync(s.small, hp, 68, hipMemcpyHostToDevice, st));
         uint32_t mask = (1u << s.fp.proof_of_work_bits) - 1u;
-        // expected 2^bits candidates: first launch covers 4x that (P[miss] = e^-4), later ones 16x
-        uint32_t batch = 1u << std::min<uint32_t>(std::max<uint32_t>(s.fp.proof_of_work_bits + 2, 10), 24);
+        // expected 2^bits candidates: first launch covers 2x that (P[miss] = e^-2), each later one 4x the previous
+        uint32_t batch = 1u << std::min<uint32_t>(std::max<uint32_t>(s.fp.proof_of_work_bits + 1, 10), 24);
         uint32_t found = 0xffffffffu;
         for (uint64_t base = 0; base < bb::P && found == 0xffffffffu; base += batch, batch = std::min<uint32_t>(batch * 4, 1u << 24)) {
             hipLaunchKernelGGL(grind_kernel, dim3(batch / 256), dim3(256), 0, st, s.small, pos, mask, (uint32_t)base, s.small + 16);

@@ -543,9 +543,17 @@ int launch_pass_t(hipStream_t stream, const PassArgs& a, uint32_t blocks) {
 
 template <int B, int MODE>
 int launch_fast_t(hipStream_t stream, const PassArgs& a, uint32_t blocks) {
-    constexpr uint32_t NPTS = 1u << B;
+    constexpr uint32_t NPTS = 1u << B, NR = B >= 9 ? 32 : 16;
     size_t lds = (size_t)NPTS * 33 * 4 + (size_t)NPTS * 4;
-    hipLaunchKernelGGL((ntt_fast_kernel<B, MODE>), dim3(blocks), dim3(NPTS * 2), lds, stream, a);
+    if constexpr (B >= 9) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            P3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_fast_kernel<B, MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL((ntt_fast_kernel<B, MODE>), dim3(blocks), dim3(NPTS * 32 / NR), lds, stream, a);
     P3_HIP(hipGetLastError());
     return OK;
 }
@@ -576,13 +584,17 @@ int launch_fast(hipStream_t stream, const PassArgs& a, uint32_t blocks, int mode
         switch (a.b) {
             case 6: return launch_fast_t<6, 2>(stream, a, blocks);
             case 7: return launch_fast_t<7, 2>(stream, a, blocks);
-            default: return launch_fast_t<8, 2>(stream, a, blocks);
+            case 8: return launch_fast_t<8, 2>(stream, a, blocks);
+            case 9: return launch_fast_t<9, 2>(stream, a, blocks);
+            default: return launch_fast_t<10, 2>(stream, a, blocks);
         }
     }
     switch (a.b) {
         case 6: return launch_fast_t<6, 3>(stream, a, blocks);
         case 7: return launch_fast_t<7, 3>(stream, a, blocks);
-        default: return launch_fast_t<8, 3>(stream, a, blocks);
+        case 8: return launch_fast_t<8, 3>(stream, a, blocks);
+        case 9: return launch_fast_t<9, 3>(stream, a, blocks);
+        default: return launch_fast_t<10, 3>(stream, a, blocks);
     }
 }
 
@@ -614,15 +626,18 @@ int launch_pass(hipStream_t stream, PassArgs& a) {
     if (blocks > 0x7fffffffull) return fail(ERR_BAD_ARG, "ntt: matrix too large for one launch");
     uint32_t nb = (uint32_t)blocks;
     static int use_fast = [] { const char* e = getenv("P3HIP_NTT_FAST"); return e ? atoi(e) : 1; }();
-    if (use_fast && log_run == 5 && a.b >= 6 && a.b <= 8) {
+    if (use_fast && log_run == 5 && a.b >= 6 && a.b <= 10) {
         int mode = pass_mode(a);
         if (mode == 2 || mode == 3) {
-            if (mode == 3 && a.has_sc) a.sc_step = bb::pow(a.sc_base, (uint64_t)((1u << a.b) / 16) << a.s0);
+            const uint32_t rows_per_lane = a.b >= 9 ? 32 : 16;
+            if (mode == 3 && a.has_sc) a.sc_step = bb::pow(a.sc_base, (uint64_t)((1u << a.b) / rows_per_lane) << a.s0);
             return launch_fast(stream, a, nb, mode);
         }
+        if (a.b > 8) goto general;
         // group-side passes: narrow widths must be powers of two for the shift-based column-wise copy
         if ((mode == 1 || (mode == 4 && !a.has_sc)) && (a.W >= 32 || a.wshift != 0xffffffffu)) return launch_fast(stream, a, nb, mode);
     }
+general:
     if (log_run == 3) return launch_pass_t<3, 5, false>(stream, a, nb);
     if (log_run == 4) return launch_pass_t<4, 5, false>(stream, a, nb);
     uint32_t log_r = a.b >= 10 ? 5 : (a.b >= 4 ? 4 : a.b);

@@ -32,11 +32,14 @@ __device__ __forceinline__ void power_ladder(uint32_t c, uint32_t phi, uint32_t 
 
 // MODE 2: DIT, in place, pre-twiddle (+ optional uniform scale on store).
 // MODE 3: DIF, in place, post-twiddle (+ optional per-row scale and zero padding on load).
+// LR = log2(rows per lane): 4 (radix-16 first round) for B <= 8, 5 (radix-32) for B = 9, 10.
 template <int B, int MODE>
-__global__ void __launch_bounds__(512) ntt_fast_kernel(PassArgs a) {
-    constexpr uint32_t RUN = 32, STRIDE = 33, NPTS = 1u << B, NTH = NPTS * 2, GSPAN = NPTS / 16;
-    constexpr int RR2 = B - 4;             // stages of the short round
-    constexpr uint32_t NSUB = 1u << (4 - RR2), SUB2 = 1u << RR2;
+__global__ void __launch_bounds__(B >= 10 ? 1024 : 512) ntt_fast_kernel(PassArgs a) {
+    constexpr int LR = B >= 9 ? 5 : 4;
+    constexpr uint32_t NR = 1u << LR;
+    constexpr uint32_t RUN = 32, STRIDE = 33, NPTS = 1u << B, NTH = NPTS * RUN / NR, GSPAN = NPTS / NR;
+    constexpr int RR2 = B - LR;            // stages of the short round
+    constexpr uint32_t NSUB = 1u << (LR - RR2), SUB2 = 1u << RR2;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* tile = smem;
     uint32_t* twl = smem + NPTS * STRIDE;
@@ -50,27 +53,27 @@ __global__ void __launch_bounds__(512) ntt_fast_kernel(PassArgs a) {
     const uint32_t lo = a.wshift != 0xffffffffu ? (uint32_t)(f >> a.wshift) : (uint32_t)(f / a.W);
     const uint64_t stride = (uint64_t)a.W << a.s0;  // words between consecutive tile rows
     const uint64_t base = ((uint64_t)hi << (a.s0 + B)) * a.W + f;
-    uint32_t v[16];
+    uint32_t v[NR];
 
     if constexpr (MODE == 2) {
         // ---- load rows pt = 16 g + j, pre-twiddle w^(rev_B(pt) * lo) ----
-        const uint32_t* p = a.src + base + (uint64_t)(g * 16) * stride;
+        const uint32_t* p = a.src + base + (uint64_t)(g * NR) * stride;
 #pragma unroll
-        for (uint32_t j = 0; j < 16; j++) v[j] = valid ? p[j * stride] : 0u;
+        for (uint32_t j = 0; j < NR; j++) v[j] = valid ? p[j * stride] : 0u;
         {
-            uint32_t c = two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)lo * rev_bits(g, B - 4));
-            uint32_t phi = two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)lo << (B - 4));
-            uint32_t pw[16];
-            power_ladder<16>(c, phi, pw);
+            uint32_t c = two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)lo * rev_bits(g, B - LR));
+            uint32_t phi = two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)lo << (B - LR));
+            uint32_t pw[NR];
+            power_ladder<(int)NR>(c, phi, pw);
 #pragma unroll
-            for (uint32_t j = 0; j < 16; j++) v[j] = bb::mul(v[j], pw[crev(j, 4)]);
+            for (uint32_t j = 0; j < NR; j++) v[j] = bb::mul(v[j], pw[crev(j, LR)]);
         }
         __syncthreads();  // twl ready
         // ---- round 1: stages 0..3 on registers ----
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < LR; u++) {
 #pragma unroll
-            for (uint32_t j0 = 0; j0 < 16; j0++) {
+            for (uint32_t j0 = 0; j0 < NR; j0++) {
                 if (j0 & (1u << u)) continue;
                 const uint32_t j1 = j0 | (1u << u);
                 const uint32_t w = twl[(1u << u) - 1u + (j0 & ((1u << u) - 1u))];
@@ -80,22 +83,22 @@ __global__ void __launch_bounds__(512) ntt_fast_kernel(PassArgs a) {
             }
         }
 #pragma unroll
-        for (uint32_t j = 0; j < 16; j++) tile[(g * 16 + j) * STRIDE + x] = v[j];
+        for (uint32_t j = 0; j < NR; j++) tile[(g * NR + j) * STRIDE + x] = v[j];
         __syncthreads();
         // ---- round 2: stages 4..B-1; pt = (ji << 4) | o, o = js * GSPAN + g ----
 #pragma unroll
         for (uint32_t js = 0; js < NSUB; js++) {
             const uint32_t o = js * GSPAN + g;
 #pragma unroll
-            for (uint32_t ji = 0; ji < SUB2; ji++) v[js * SUB2 + ji] = tile[((ji << 4) | o) * STRIDE + x];
+            for (uint32_t ji = 0; ji < SUB2; ji++) v[js * SUB2 + ji] = tile[((ji << LR) | o) * STRIDE + x];
 #pragma unroll
             for (int u = 0; u < RR2; u++) {
-                const uint32_t k = 4 + u;
+                const uint32_t k = LR + u;
 #pragma unroll
                 for (uint32_t ji = 0; ji < SUB2; ji++) {
                     if (ji & (1u << u)) continue;
                     const uint32_t j0 = js * SUB2 + ji, j1 = j0 | (1u << u);
-                    const uint32_t w = twl[(1u << k) - 1u + ((ji & ((1u << u) - 1u)) << 4) + o];
+                    const uint32_t w = twl[(1u << k) - 1u + ((ji & ((1u << u) - 1u)) << LR) + o];
                     uint32_t t = bb::mul(v[j1], w), s = v[j0];
                     v[j0] = bb::add(s, t);
                     v[j1] = bb::sub(s, t);
@@ -110,7 +113,7 @@ __global__ void __launch_bounds__(512) ntt_fast_kernel(PassArgs a) {
             for (uint32_t ji = 0; ji < SUB2; ji++) {
                 uint32_t val = v[js * SUB2 + ji];
                 if (a.has_us) val = bb::mul(val, a.uscale);
-                q[(uint64_t)((ji << 4) | (js * GSPAN + g)) * stride] = val;
+                q[(uint64_t)((ji << LR) | (js * GSPAN + g)) * stride] = val;
             }
     } else {
         // ---- DIF: load rows pt = (j << (B-4)) | g (zero padding / row scale on the first forward pass) ----
@@ -118,32 +121,32 @@ __global__ void __launch_bounds__(512) ntt_fast_kernel(PassArgs a) {
         const uint64_t drow = (uint64_t)GSPAN << a.s0;  // rows between consecutive j
         const uint32_t* p = a.src + base + (uint64_t)g * stride;
 #pragma unroll
-        for (uint32_t j = 0; j < 16; j++) v[j] = (valid && row0 + j * drow < a.src_rows) ? p[(uint64_t)(j * GSPAN) * stride] : 0u;
+        for (uint32_t j = 0; j < NR; j++) v[j] = (valid && row0 + j * drow < a.src_rows) ? p[(uint64_t)(j * GSPAN) * stride] : 0u;
         if (a.has_sc && valid && row0 < a.src_rows) {
             // sc(row) = mult * shift^row: c_j = sc(row0) * (shift^drow)^j
             uint32_t c = two_level(a.sc_lo, a.sc_hi, a.sc_T, row0);
-            uint32_t pw[16];
-            power_ladder<16>(c, a.sc_step, pw);
+            uint32_t pw[NR];
+            power_ladder<(int)NR>(c, a.sc_step, pw);
 #pragma unroll
-            for (uint32_t j = 0; j < 16; j++) v[j] = bb::mul(v[j], pw[j]);  // rows beyond src_rows hold 0 already
+            for (uint32_t j = 0; j < NR; j++) v[j] = bb::mul(v[j], pw[j]);  // rows beyond src_rows hold 0 already
         }
         __syncthreads();  // twl ready
         // ---- round A: stages B-1..B-4 on registers (k0 = B-4, low bits of pt = g) ----
 #pragma unroll
-        for (int u = 3; u >= 0; u--) {
-            const uint32_t k = (B - 4) + u;
+        for (int u = LR - 1; u >= 0; u--) {
+            const uint32_t k = (B - LR) + u;
 #pragma unroll
-            for (uint32_t j0 = 0; j0 < 16; j0++) {
+            for (uint32_t j0 = 0; j0 < NR; j0++) {
                 if (j0 & (1u << u)) continue;
                 const uint32_t j1 = j0 | (1u << u);
-                const uint32_t w = twl[(1u << k) - 1u + ((j0 & ((1u << u) - 1u)) << (B - 4)) + g];
+                const uint32_t w = twl[(1u << k) - 1u + ((j0 & ((1u << u) - 1u)) << (B - LR)) + g];
                 uint32_t s = v[j0], c = v[j1];
                 v[j0] = bb::add(s, c);
                 v[j1] = bb::mul(bb::sub(s, c), w);
             }
         }
 #pragma unroll
-        for (uint32_t j = 0; j < 16; j++) tile[((j << (B - 4)) | g) * STRIDE + x] = v[j];
+        for (uint32_t j = 0; j < NR; j++) tile[((j << (B - LR)) | g) * STRIDE + x] = v[j];
         __syncthreads();
         // ---- round B: stages RR2-1..0; pt = (o << RR2) | ji ----
         const uint32_t phi = two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)lo << (B - RR2));

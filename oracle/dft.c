@@ -5,7 +5,25 @@
 #include "bb31.h"
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
+/* threads used by the OpenMP loops (1 = the reference build's single thread) */
+void p3o_set_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n > 0 ? n : 1);
+#else
+    (void)n;
+#endif
+}
+int p3o_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_num_procs();
+#else
+    return 1;
+#endif
+}
 uint32_t p3o_to_monty(uint32_t c) { return bb_to_monty(c); }
 uint32_t p3o_from_monty(uint32_t m) { return bb_from_monty(m); }
 uint32_t p3o_add(uint32_t a, uint32_t b) { return bb_add(a, b); }

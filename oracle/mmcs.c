@@ -80,12 +80,15 @@ p3o_tree_t *p3o_mmcs_commit(const uint32_t *const *mats, const size_t *heights,
     t->layers = malloc(t->n_layers * sizeof(uint32_t *));
     t->layer_len[0] = maxh;
     t->layers[0] = malloc(maxh * 32);
+    /* rows are independent: optional OpenMP for the multi-core CPU baseline (p3o_set_threads) */
+    #pragma omp parallel for schedule(static)
     for (size_t r = 0; r < maxh; r++) hash_rows_of_height(t, maxh, r, t->layers[0] + r * 8);
     for (size_t l = 1; l < t->n_layers; l++) {
         size_t len = t->layer_len[l - 1] / 2;
         t->layer_len[l] = len;
         t->layers[l] = malloc(len * 32);
         int inject = has_height(t, len);
+        #pragma omp parallel for schedule(static) if (len >= 256)
         for (size_t i = 0; i < len; i++) {
             uint32_t d[8];
             p3o_compress(t->layers[l - 1] + 2 * i * 8, t->layers[l - 1] + (2 * i + 1) * 8, d);

@@ -37,6 +37,7 @@ def lib():
             build()
         _lib = C.CDLL(_LIB_PATH)
         L = _lib
+        L.p3o_set_threads(C.c_int(1))  # serial by default, like the reference's build (no `parallel` feature)
         for name in ("p3o_to_monty", "p3o_from_monty", "p3o_inv"):
             getattr(L, name).restype = C.c_uint32
             getattr(L, name).argtypes = [C.c_uint32]
@@ -203,6 +204,15 @@ def mmcs_verify_batch(root, dims, index, rows, path):
     path = _u32(path).reshape(-1, 8)
     return lib().p3o_mmcs_verify_batch(_p(_u32(root)), hs, ws, C.c_size_t(n), C.c_size_t(index),
                                        _p(rows), _p(path), C.c_size_t(path.shape[0])) == 0
+
+
+def set_threads(n):
+    """Threads of the oracle's OpenMP loops; 1 reproduces the reference's serial CPU build."""
+    lib().p3o_set_threads(C.c_int(int(n)))
+
+
+def max_threads():
+    return int(lib().p3o_max_threads())
 
 
 # ---- fib_air prover / verifier (stark.c) ----

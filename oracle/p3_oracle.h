@@ -9,6 +9,10 @@
 extern "C" {
 #endif
 
+/* OpenMP thread count of the hashing / transform loops (default: all cores; 1 = the reference's serial build) */
+void p3o_set_threads(int n);
+int p3o_max_threads(void);
+
 /* ---- field helpers exported for python tests ---- */
 uint32_t p3o_to_monty(uint32_t canon);
 uint32_t p3o_from_monty(uint32_t monty);

@@ -115,6 +115,7 @@ static void fold_matrix(const bb4_t *in, size_t len, bb4_t beta, bb4_t *out) {
     uint32_t *pw = malloc((half ? half : 1) * 4);
     uint32_t acc = BB_ONE;
     for (size_t i = 0; i < half; i++) { pw[i] = acc; acc = bb_mul(acc, ginv); }
+    #pragma omp parallel for schedule(static) if (half >= 4096)
     for (size_t i = 0; i < half; i++) {
         bb4_t power = bb4_scale(hb, pw[rev_bits(i, lh)]);
         bb4_t oh = bb4_from_base(one_half);
@@ -158,16 +159,19 @@ int p3o_prove_fib_air(uint64_t a, uint64_t b, unsigned log_n, unsigned log_blowu
     uint32_t *qflat = malloc(n * 4 * 4);
     { uint32_t g = bb_two_adic_generator(log_n), ginv = bb_inv(g);
       uint32_t zh = bb_sub(bb_pow(gen, n), BB_ONE), zh_inv = bb_inv(zh);
-      uint32_t x = gen;
+      uint32_t *xq = malloc(n * 4);
+      { uint32_t xx = gen; for (size_t i = 0; i < n; i++) { xq[i] = xx; xx = bb_mul(xx, g); } }
+      #pragma omp parallel for schedule(static)
       for (size_t i = 0; i < n; i++) {
+          uint32_t x = xq[i];
           const uint32_t *loc = lde_t + rev_bits(i, log_n) * 2, *nxt = lde_t + rev_bits((i + 1) & (n - 1), log_n) * 2;
           uint32_t first = bb_mul(zh, bb_inv(bb_sub(x, BB_ONE)));
           uint32_t last = bb_mul(zh, bb_inv(bb_sub(x, ginv)));
           uint32_t trans = bb_sub(x, ginv);
           bb4_t q = bb4_scale(fib_fold_base(loc, nxt, pis, first, last, trans, apow), zh_inv);
           memcpy(qflat + 4 * i, q.c, 16);
-          x = bb_mul(x, g);
-      } }
+      }
+      free(xq); }
     /* commit quotient chunk: domain shift = GENERATOR so the LDE shift is GENERATOR/GENERATOR = 1 */
     uint32_t *lde_q = malloc(big * 4 * 4);
     p3o_coset_lde_batch(qflat, lde_q, n, 4, log_blowup, BB_ONE, 1);
@@ -195,6 +199,7 @@ int p3o_prove_fib_air(uint64_t a, uint64_t b, unsigned log_n, unsigned log_blowu
       uint32_t g = bb_two_adic_generator(log_big);
       uint32_t *xs = malloc(big * 4); uint32_t x = gen;
       for (size_t i = 0; i < big; i++) { xs[i] = x; x = bb_mul(x, g); }
+      #pragma omp parallel for schedule(static)
       for (size_t i = 0; i < big; i++) {
           uint32_t xi = xs[rev_bits(i, log_big)];
           bb4_t rt = bb4_zero(), rq = bb4_zero();

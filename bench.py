@@ -38,7 +38,12 @@ def cpu_baseline(log_height, log_blowup, job):
     proof = o.prove_fib_air(0, 1, log_height, fp)
     dt = time.perf_counter() - t0
     # the same port with its OpenMP loops (Merkle layers, quotient, openings, folds) on every host core
-    cores = o.max_threads()
+    # the GPU box gives one GPU's job a share of about 16 host cores whatever nproc says
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = o.max_threads()
+    cores = max(1, min(o.max_threads(), avail, int(os.environ.get("P3HIP_BENCH_CPU_THREADS", "16"))))
     o.set_threads(cores)
     t1 = time.perf_counter()
     proof_mt = o.prove_fib_air(0, 1, log_height, fp)

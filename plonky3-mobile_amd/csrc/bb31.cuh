@@ -49,7 +49,7 @@ BB_HD uint32_t monty_reduce(uint64_t x) {
 }
 // Montgomery product.  lo/hi are taken with separate v_mul_lo_u32 / v_mul_hi_u32: hipcc otherwise fuses the
 // 64-bit product into v_mad_u64_u32, which issues ~3x slower than the pair on gfx950
-// (profiles/r01_microbench_int_valu.txt).
+// (profiles/r01_microbench2_valu_issue_rates.txt).
 BB_HD uint32_t mul(uint32_t a, uint32_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     uint32_t lo = a * b, hi = __umulhi(a, b);

@@ -687,6 +687,15 @@ int run_dit(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* dst,
 int run_dif(Context& cx, hipStream_t stream, const uint32_t* src, uint64_t src_rows, uint32_t* dst, uint32_t n,
             uint32_t W, bool inverse, const TwoLevelTable* sc, uint32_t sc_base, bool natural_out) {
     std::vector<uint32_t> digits = split_digits(n);  // lowest first; DIF walks them top-down
+    // The natural-order last pass SCATTERS rows (group h0 writes rows that belong to other groups' inputs), so it
+    // cannot run in place: with more than one pass the earlier passes work in scratch and the last one goes
+    // scratch -> dst.  (Bit-reversed output stays in place: every pass rewrites exactly the rows it read.)
+    uint32_t* work = dst;
+    if (natural_out && digits.size() > 1) {
+        int rc = cx.ws[0].reserve(((size_t)W << n) * 4);
+        if (rc) return rc;
+        work = cx.ws[0].as<uint32_t>();
+    }
     uint32_t s0 = n;
     for (size_t ii = digits.size(); ii-- > 0;) {
         bool first = ii + 1 == digits.size(), last = ii == 0;
@@ -694,8 +703,8 @@ int run_dif(Context& cx, hipStream_t stream, const uint32_t* src, uint64_t src_r
         PassArgs a{};
         a.W = W; a.n = n; a.b = digits[ii]; a.s0 = s0; a.dif = 1;
         a.tile_tw = cx.tile_tw[inverse ? 1 : 0];
-        a.src = first ? src : dst;
-        a.dst = dst;
+        a.src = first ? src : work;
+        a.dst = last ? dst : work;
         a.src_rows = first ? src_rows : (1ull << n);
         if (first && sc) { a.has_sc = 1; a.sc_lo = sc->lo; a.sc_hi = sc->hi; a.sc_T = sc->T; a.sc_base = sc_base; }
         if (!last) { a.load_kind = SIDE_INPLACE; a.store_kind = SIDE_INPLACE; }
@@ -708,7 +717,6 @@ int run_dif(Context& cx, hipStream_t stream, const uint32_t* src, uint64_t src_r
     }
     return OK;
 }
-
 
 template <int BI, int A>
 int launch_fused_mid_t(hipStream_t stream, const PassArgs& a, uint32_t blocks) {

@@ -85,3 +85,24 @@ def test_mmcs_rejects_bad_input(p3):
     mm = p3.MerkleTreeMmcs()
     with pytest.raises(p3.P3HipError):
         mm.commit([np.zeros((12, 2), np.uint32)])
+
+
+def test_mmcs_randomized_dims(p3, oracle):
+    """Seeded random commitments: 1-4 matrices of random power-of-two heights and random widths (injection
+    at arbitrary layers, lane-cooperative and one-state-per-lane layers mixed), roots and openings vs oracle."""
+    rng = np.random.default_rng(77)
+    mm = p3.MerkleTreeMmcs()
+    for it in range(40):
+        k = int(rng.integers(1, 5))
+        dims = [(1 << int(rng.integers(0, 17)), int(rng.integers(1, 20))) for _ in range(k)]
+        dims = [(h, min(w, max(1, (1 << 18) // h))) for h, w in dims]
+        mats = [_rand(rng, h, w) for h, w in dims]
+        root, tree = mm.commit(mats)
+        oroot, otree = oracle.mmcs_commit(mats)
+        assert np.array_equal(root, oroot), (it, dims)
+        maxh = max(h for h, _ in dims)
+        idx = int(rng.integers(0, maxh))
+        rows, path = mm.open_batch(idx, tree)
+        orows, opath = otree.open_batch(idx)
+        assert np.array_equal(np.concatenate(rows), orows) and np.array_equal(path, opath), (it, dims, idx)
+        tree.free()

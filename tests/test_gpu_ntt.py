@@ -166,3 +166,26 @@ def test_keccak_air_shaped_wide_matrix(dft, oracle, p3):
     root, _ = p3.MerkleTreeMmcs().commit([got])
     oroot, _ = oracle.mmcs_commit([exp])
     assert np.array_equal(root, oroot)
+
+
+def test_randomized_shapes_sweep(dft, oracle, p3):
+    """Seeded random sweep over (log height, width, blowup, shift, output order): every plan shape the
+    planner can pick for heights up to 2^15 (single pass, two and three passes, fused middle, fast and
+    general kernels, power-of-two and odd widths)."""
+    rng = np.random.default_rng(20261004)
+    for it in range(120):
+        log_h = int(rng.integers(0, 16))
+        w = int(rng.choice([1, 2, 3, 4, 6, 8, 16, 24, 32, 33, 48, 64, 100]))
+        if (1 << log_h) * w > 1 << 20:
+            w = max(1, (1 << 20) >> log_h)
+        ab = int(rng.integers(0, 4))
+        if log_h + ab > 17:
+            ab = 17 - log_h
+        shift = int(rng.choice([p3.GENERATOR_MONTY, p3.MONTY_ONE, int(rng.integers(1, P))]))
+        x = _rand(rng, 1 << log_h, w)
+        br = bool(rng.integers(0, 2))
+        exp = oracle.coset_lde_batch(x, ab, shift, br)
+        got = dft.coset_lde_batch(x, ab, shift, bit_reversed_out=br)
+        assert np.array_equal(got, exp), (it, log_h, w, ab, br)
+        if it % 3 == 0:
+            assert np.array_equal(dft.dft_batch(x), oracle.dft_batch(x)), (it, log_h, w)

@@ -189,3 +189,21 @@ def test_randomized_shapes_sweep(dft, oracle, p3):
         assert np.array_equal(got, exp), (it, log_h, w, ab, br)
         if it % 3 == 0:
             assert np.array_equal(dft.dft_batch(x), oracle.dft_batch(x)), (it, log_h, w)
+
+
+def test_randomized_large_shapes(dft, oracle, p3):
+    """A handful of seeded random large cases (2^16..2^20 rows) against the oracle: three-pass plans, the fused
+    middle pass (blowup 2 and 4), 9- and 10-stage tiles, natural and bit-reversed output."""
+    rng = np.random.default_rng(424242)
+    cases = [(16, 3, 1, True), (17, 2, 2, False), (18, 4, 1, True), (18, 1, 2, True), (19, 2, 1, False), (20, 2, 1, True),
+             (20, 4, 2, True), (16, 40, 3, False), (19, 8, 0, True)]
+    for log_h, w, ab, br in cases:
+        x = _rand(rng, 1 << log_h, w)
+        shift = int(rng.choice([p3.GENERATOR_MONTY, int(rng.integers(1, P))]))
+        exp = oracle.coset_lde_batch(x, ab, shift, br)
+        got = dft.coset_lde_batch(x, ab, shift, bit_reversed_out=br)
+        assert np.array_equal(got, exp), (log_h, w, ab, br)
+    x = _rand(rng, 1 << 19, 3)
+    y = oracle.dft_batch(x)
+    assert np.array_equal(dft.dft_batch(x), y)
+    assert np.array_equal(dft.idft_batch(y), x)

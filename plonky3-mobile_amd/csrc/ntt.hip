@@ -16,6 +16,8 @@
 // Row-major H x W matrices of Montgomery words, exactly the buffers the reference uploads
 // (backend_vulkan.rs:2002-2005).  Stage semantics inside a tile are those of cpu_stage_u32_in_place
 // (backend_vulkan.rs:881-942) with the same twiddle-table layout (:977-996: stage k at offset 2^k-1).
+#include <algorithm>
+
 #include "bb31.cuh"
 #include "common.h"
 
@@ -494,6 +496,10 @@ std::vector<uint32_t> split_digits(uint32_t n) {
         d.push_back(b);
         rem -= b;
     }
+    // The contiguous-group pass (lowest digit) has lean kernels up to 8 stages, the in-place passes up to 10:
+    // when a digit exceeds 8 put the smallest digit lowest; otherwise the largest (measured faster for narrow
+    // matrices: fewer, fatter group tiles).
+    if (d.front() > 8) std::reverse(d.begin(), d.end());
     return d;
 }
 

@@ -90,7 +90,7 @@ __device__ __forceinline__ void permute(double (&s)[16]) {
         // the integer-multiplier lanes grow ~4x per round: fold them back every round pair (cheap: 3 ops each)
         if (r & 1) {
             s[1] = reduce(s[1]); s[2] = reduce(s[2]); s[4] = reduce(s[4]); s[5] = reduce(s[5]);
-            s[7] = reduce(s[7]); s[8] = reduce(s[8]);
+            s[7] = reduce(s[7]); s[8] = reduce(s[8]); s[12] = reduce(s[12]); s[15] = reduce(s[15]);
         }
         double tot = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7])) +
                      (((s[8] + s[9]) + (s[10] + s[11])) + ((s[12] + s[13]) + (s[14] + s[15])));
@@ -107,10 +107,10 @@ __device__ __forceinline__ void permute(double (&s)[16]) {
         s[9] = tot + mulmod(s[9], d_c.frac[9]);
         s[10] = tot + mulmod(s[10], d_c.frac[10]);
         s[11] = tot + mulmod(s[11], d_c.frac[11]);
-        s[12] = tot + mulmod(s[12], d_c.frac[12]);
+        s[12] = __fma_rn(s[12], -15.0, tot);  // 2^-27 = -15 (mod P) because P - 1 = 15 * 2^27
         s[13] = tot + mulmod(s[13], d_c.frac[13]);
         s[14] = tot + mulmod(s[14], d_c.frac[14]);
-        s[15] = tot + mulmod(s[15], d_c.frac[15]);
+        s[15] = __fma_rn(s[15], 15.0, tot);   // -2^-27 = 15
     }
     _Pragma("clang loop unroll(disable)")
     for (int r = 4; r < 8; r++) {

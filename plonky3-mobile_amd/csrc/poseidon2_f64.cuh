@@ -20,18 +20,39 @@ __device__ __forceinline__ double mulmod(double a, double b) {
     double r = __fma_rn(-q, PD, h);
     return r + l;
 }
+// a * b (mod P) when aP = a / P is already known: q = rint(b * aP) is within 1 of a*b/P; q * (P - 1) =
+// q * 15 * 2^27 is exact, so t = fma(a, b, -q(P-1)) = (ab - qP) + q is an integer below 2^33, hence exact.
+// Five ops, |result| <= P/2 + 1 + |ab| 2^-52.  Exact while |ab| < 2^76.
+constexpr double PM1 = 2013265920.0;
+__device__ __forceinline__ double mulmod_p(double a, double b, double aP) {
+    double q = __builtin_rint(b * aP);
+    double t = __fma_rn(a, b, -(q * PM1));
+    return t - q;
+}
 __device__ __forceinline__ double reduce(double x) {  // |result| <= P/2 + eps
     return __fma_rn(-__builtin_rint(x * PINV), PD, x);
 }
+// tot + x * 2^-K (mod P), K <= 8, for integers |x| < 2^44, |tot| < 2^40: xt = tot + x / 2^K is exact (K fractional
+// bits), fract(xt) = (x mod 2^K) / 2^K because tot is an integer, and xt - fract * P = tot + (x - (x mod 2^K) P) / 2^K
+// is an integer (P = 1 mod 2^K) below 2^45: three exact ops.  inv = +-2^-K.
+__device__ __forceinline__ double add_scaled_pow2(double tot, double x, double inv) {
+    double xt = __fma_rn(x, inv, tot);
+    double fr = __builtin_amdgcn_fract(xt);
+    return __fma_rn(fr, -PD, xt);
+}
+// x^7: x2 = x*x, x3 = x2*x, x4 = x3*x share xP = x / P; the last product pays for its own quotient estimate.
 __device__ __forceinline__ double sbox7(double x) {
-    double x2 = mulmod(x, x), x3 = mulmod(x2, x), x4 = mulmod(x2, x2);
+    double xP = x * PINV;
+    double x2 = mulmod_p(x, x, xP), x3 = mulmod_p(x, x2, xP), x4 = mulmod_p(x, x3, xP);
     return mulmod(x3, x4);
 }
 
 struct ConstsF64 {
     double ext[8][16];
     double in[13];
-    double frac[16];  // canonical value of V[i] for the fractional diagonal entries, 0 elsewhere
+    // multipliers of the internal diagonal that are not fp64 inline constants, kept in SGPRs (as literals the
+    // compiler would pick v_fmac + a copy of the addend): 3, 15, 2^-2, 2^-3, 2^-4, 2^-8
+    double k3, k15, i4, i8, i16, i256;
 };
 constexpr uint32_t c_from_monty(uint32_t m) {  // m * 2^-32 mod P
     uint32_t t = m * bb::MU;
@@ -48,12 +69,7 @@ constexpr ConstsF64 make_consts() {
             c.ext[4 + r][i] = (double)c_from_monty(P3_RC16_EXT_FINAL_MONTY[r][i]);
         }
     for (int r = 0; r < 13; r++) c.in[r] = (double)c_from_monty(P3_RC16_INTERNAL_MONTY[r]);
-    uint64_t i2 = c_powmod(2, bb::P - 2);
-    // V = [-2, 1, 2, 1/2, 3, 4, -1/2, -3, -4, 2^-8, 1/4, 1/8, 2^-27, -2^-8, -1/16, -2^-27]
-    c.frac[3] = (double)i2; c.frac[6] = (double)(bb::P - i2);
-    c.frac[9] = (double)c_powmod(i2, 8); c.frac[10] = (double)c_powmod(i2, 2); c.frac[11] = (double)c_powmod(i2, 3);
-    c.frac[12] = (double)c_powmod(i2, 27); c.frac[13] = (double)(bb::P - c_powmod(i2, 8));
-    c.frac[14] = (double)(bb::P - c_powmod(i2, 4)); c.frac[15] = (double)(bb::P - c_powmod(i2, 27));
+    c.k3 = 3.0; c.k15 = 15.0; c.i4 = 0.25; c.i8 = 0.125; c.i16 = 0.0625; c.i256 = 0.00390625;
     return c;
 }
 static __device__ __constant__ ConstsF64 d_c = make_consts();
@@ -84,34 +100,44 @@ __device__ __forceinline__ void permute(double (&s)[16]) {
         for (int i = 0; i < 16; i++) s[i] = sbox7(s[i] + d_c.ext[r][i]);  // |.| < 1.1 P
         external_linear(s);                                                // < 39 P < 2^37
     }
-    _Pragma("clang loop unroll(disable)")
-    for (int r = 0; r < 13; r++) {
+    // V = [-2, 1, 2, 1/2, 3, 4, -1/2, -3, -4, 2^-8, 1/4, 1/8, 2^-27, -2^-8, -1/16, -2^-27]; 2^-27 = -15 (mod P)
+    // because P - 1 = 15 * 2^27.  The integer-multiplier lanes grow up to 15x per round: fold them back after
+    // every fourth round (15^4 * 2^31 < 2^47); the fractional lanes stay below 3P by themselves.
+    const double k3 = d_c.k3, k15 = d_c.k15, i4 = d_c.i4, i8 = d_c.i8, i16 = d_c.i16, i256 = d_c.i256;
+    auto internal_round = [&](int r) {
         s[0] = sbox7(s[0] + d_c.in[r]);
-        // the integer-multiplier lanes grow ~4x per round: fold them back every round pair (cheap: 3 ops each)
-        if (r & 1) {
-            s[1] = reduce(s[1]); s[2] = reduce(s[2]); s[4] = reduce(s[4]); s[5] = reduce(s[5]);
-            s[7] = reduce(s[7]); s[8] = reduce(s[8]); s[12] = reduce(s[12]); s[15] = reduce(s[15]);
-        }
         double tot = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7])) +
                      (((s[8] + s[9]) + (s[10] + s[11])) + ((s[12] + s[13]) + (s[14] + s[15])));
         tot = reduce(tot);
         s[0] = __fma_rn(s[0], -2.0, tot);
         s[1] = tot + s[1];
         s[2] = __fma_rn(s[2], 2.0, tot);
-        s[3] = tot + mulmod(s[3], d_c.frac[3]);
-        s[4] = __fma_rn(s[4], 3.0, tot);
+        s[3] = add_scaled_pow2(tot, s[3], 0.5);
+        s[4] = __fma_rn(s[4], k3, tot);
         s[5] = __fma_rn(s[5], 4.0, tot);
-        s[6] = tot + mulmod(s[6], d_c.frac[6]);
-        s[7] = __fma_rn(s[7], -3.0, tot);
+        s[6] = add_scaled_pow2(tot, s[6], -0.5);
+        s[7] = __fma_rn(s[7], -k3, tot);
         s[8] = __fma_rn(s[8], -4.0, tot);
-        s[9] = tot + mulmod(s[9], d_c.frac[9]);
-        s[10] = tot + mulmod(s[10], d_c.frac[10]);
-        s[11] = tot + mulmod(s[11], d_c.frac[11]);
-        s[12] = __fma_rn(s[12], -15.0, tot);  // 2^-27 = -15 (mod P) because P - 1 = 15 * 2^27
-        s[13] = tot + mulmod(s[13], d_c.frac[13]);
-        s[14] = tot + mulmod(s[14], d_c.frac[14]);
-        s[15] = __fma_rn(s[15], 15.0, tot);   // -2^-27 = 15
+        s[9] = add_scaled_pow2(tot, s[9], i256);
+        s[10] = add_scaled_pow2(tot, s[10], i4);
+        s[11] = add_scaled_pow2(tot, s[11], i8);
+        s[12] = __fma_rn(s[12], -k15, tot);
+        s[13] = add_scaled_pow2(tot, s[13], -i256);
+        s[14] = add_scaled_pow2(tot, s[14], -i16);
+        s[15] = __fma_rn(s[15], k15, tot);
+    };
+    auto fold_integer_lanes = [&]() {
+        s[1] = reduce(s[1]); s[2] = reduce(s[2]); s[4] = reduce(s[4]); s[5] = reduce(s[5]);
+        s[7] = reduce(s[7]); s[8] = reduce(s[8]); s[12] = reduce(s[12]); s[15] = reduce(s[15]);
+    };
+    _Pragma("clang loop unroll(disable)")
+    for (int blk = 0; blk < 3; blk++) {
+        _Pragma("clang loop unroll(disable)")
+        for (int r = 0; r < 4; r++) internal_round(4 * blk + r);
+        fold_integer_lanes();
     }
+    internal_round(12);
+    fold_integer_lanes();
     _Pragma("clang loop unroll(disable)")
     for (int r = 4; r < 8; r++) {
 #pragma unroll

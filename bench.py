@@ -184,10 +184,12 @@ def main():
         # The kernel that dominates a proof BY TIME is Poseidon2 (12.6 M permutations per 2^20 proof, ~80 % of the GPU
         # time) and it is integer-VALU-bound, which the contract's hbm|mfma roofline cannot express: reported here
         # against the issue ceiling derived from the measured per-instruction rates.
-        "valu_roofline": {"kernel": "Poseidon2 leaf/compress (one state per lane)", "achieved": job.poseidon2_rate() / 1e9,
-                          "peak": 6.4, "unit": "Gperm/s", "instructions_per_permutation": 7229,
-                          "peak_basis": "3.2k full-rate (2.45 cyc) + 4.0k half-rate (4.2 cyc) wave-instructions per "
-                                        "permutation on 1024 SIMDs at 2.4 GHz (profiles/r01_microbench2_valu_issue_rates.txt)"},
+        "valu_roofline": {"kernel": "Poseidon2 leaf/compress (one state per lane, fp64 integer arithmetic)",
+                          "achieved": job.poseidon2_rate() / 1e9,
+                          "peak": 7.26, "unit": "Gperm/s", "instructions_per_permutation": 5156,
+                          "peak_basis": "5.16k wave-instructions per permutation (ISA count of compress_layer_f64_kernel), "
+                                        "nearly all fp64 VALU at 4.2 cycles each, on 1024 SIMDs at 2.4 GHz "
+                                        "(profiles/r01_microbench2_valu_issue_rates.txt)"},
         "stages_ms": job.stage_breakdown(),
         "collectives": coll_state["mode"],
     }

@@ -49,7 +49,7 @@ struct TwoLevelTable {  // value(e) = lo[e & (2^T - 1)] * hi[e >> T]
 
 struct Context {
     int device = -1;
-    uint32_t* tile_tw[2] = {nullptr, nullptr};  // [inverse]: reference-layout stage tables, 2^11-1 words
+    uint32_t* tile_tw[2] = {nullptr, nullptr};  // [inverse]: reference-layout stage tables, 2^12-1 words
     std::map<std::pair<uint32_t, int>, TwoLevelTable> root_tables;            // (q, inverse) -> w_{2^q}^e
     std::map<std::tuple<uint32_t, uint32_t, uint32_t>, TwoLevelTable> scale_tables;  // (base, log_n, mult)
     DevBuf ws[4];  // scratch slabs (ntt ping-pong, lde coefficients, ...)

@@ -60,10 +60,10 @@ int Context::init() {
     int dev = 0;
     P3_HIP(hipGetDevice(&dev));
     // Stage tables in the reference's layout (backend_vulkan.rs:977-996): stage k at offset 2^k - 1 holds
-    // w_{2^(k+1)}^e, e < 2^k.  One table of 11 stages serves every tile size (prefix property).
+    // w_{2^(k+1)}^e, e < 2^k.  One table of 12 stages serves every tile size (prefix property).
     for (int invs = 0; invs < 2; invs++) {
-        std::vector<uint32_t> t(1u << 11, 0);
-        for (uint32_t k = 0; k < 11; k++) {
+        std::vector<uint32_t> t(1u << 12, 0);
+        for (uint32_t k = 0; k < 12; k++) {
             uint32_t root = bb::two_adic_generator(k + 1);
             if (invs) root = bb::inv(root);
             uint32_t acc = bb::ONE;

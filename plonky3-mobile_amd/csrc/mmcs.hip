@@ -275,7 +275,7 @@ __global__ void poseidon2_permute_f64_kernel(uint32_t* states, uint64_t n) {
 }
 
 int poseidon2_permute_states(hipStream_t stream, uint32_t* d_states, uint64_t n) {
-    static int use_f64 = [] { const char* e = getenv("P3HIP_P2_F64"); return e ? atoi(e) : 0; }();
+    static int use_f64 = [] { const char* e = getenv("P3HIP_P2_F64"); return e ? atoi(e) : 1; }();
     static int use_x2 = [] { const char* e = getenv("P3HIP_P2_X2"); return e ? atoi(e) : 0; }();
     if (n && use_x2) {
         uint64_t half = (n + 1) / 2;

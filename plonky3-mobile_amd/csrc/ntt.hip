@@ -133,6 +133,7 @@ __device__ __forceinline__ uint32_t two_level(const uint32_t* lo, const uint32_t
 
 }  // namespace p3
 #include "ntt_fast.cuh"
+#include "ntt_narrow.cuh"
 namespace p3 {
 
 // Decodes a copy-loop index into tile coordinates (pt, x), the global word offset and the natural row
@@ -819,6 +820,86 @@ int lde_fused(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* ds
     return OK;
 }
 
+
+template <int B, int K>
+int launch_narrow_t(hipStream_t stream, const NarrowArgs& a, uint32_t blocks) {
+    constexpr size_t lds = ((size_t)1 << B) * narrow::NQ * 8;
+    auto kern = K == 1 ? narrow_inv1_kernel<B> : (K == 2 ? narrow_mid_kernel<B> : narrow_fwd2_kernel<B>);
+    if constexpr (lds > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            P3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(1u << (B - 2)), lds, stream, a);
+    P3_HIP(hipGetLastError());
+    return OK;
+}
+template <int K>
+int launch_narrow(hipStream_t stream, const NarrowArgs& a, uint32_t b, uint32_t blocks) {
+    switch (b) {
+        case 8: return launch_narrow_t<8, K>(stream, a, blocks);
+        case 9: return launch_narrow_t<9, K>(stream, a, blocks);
+        case 10: return launch_narrow_t<10, K>(stream, a, blocks);
+        case 11: return launch_narrow_t<11, K>(stream, a, blocks);
+        case 12: return launch_narrow_t<12, K>(stream, a, blocks);
+        default: return fail(ERR_INTERNAL, "lde_narrow: digit out of range");
+    }
+}
+
+// Narrow-matrix coset LDE in three launches (ntt_narrow.cuh).  Returns 1 when the shape is not covered.
+int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* dst, uint32_t n, uint32_t added, uint32_t W,
+               uint32_t shift, bool bit_reversed_out) {
+    static int enabled = [] { const char* e = getenv("P3HIP_NTT_NARROW"); return e ? atoi(e) : 1; }();
+    static uint32_t n_min = [] { const char* e = getenv("P3HIP_NTT_NARROW_MIN"); return e ? (uint32_t)atoi(e) : 16u; }();
+    if (!enabled || !bit_reversed_out || added < 1 || added > 3) return 1;
+    if (W != 2 && W != 4 && W != 8) return 1;
+    if (n < n_min || n < 16 || n > 24) return 1;
+    if ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 7u) return 1;  // 8-byte accesses
+    const uint32_t n1 = (n + 1) / 2, n2 = n - n1;
+    const uint64_t N = 1ull << n;
+    int rc = cx.ws[1].reserve(N * W * 4);
+    if (rc) return rc;
+    uint32_t* T = cx.ws[1].as<uint32_t>();
+    NarrowArgs a{};
+    a.n = n; a.n1 = n1; a.n2 = n2; a.W = W; a.wsl = log2u(W / 2); a.added = added;
+    TwoLevelTable ti, tf;
+    if ((rc = cx.get_root_table(n, true, &ti))) return rc;
+    if ((rc = cx.get_root_table(n, false, &tf))) return rc;
+    const uint32_t wslots = W / 2;
+    // K1
+    a.src = src; a.dst = T;
+    a.stage_tw = cx.tile_tw[1];
+    a.tw_lo = ti.lo; a.tw_hi = ti.hi; a.tw_T = ti.T;
+    uint32_t tiles = (uint32_t)(((1ull << n2) * wslots) / narrow::NQ);
+    a.xcd_remap = tiles % 32 == 0;
+    if ((rc = launch_narrow<1>(stream, a, n1, tiles))) return rc;
+    // K2
+    a.src = T; a.dst = dst;
+    a.stage_tw = cx.tile_tw[1]; a.stage_tw_fwd = cx.tile_tw[0];
+    a.twf_lo = tf.lo; a.twf_hi = tf.hi; a.twf_T = tf.T;
+    const uint32_t hinv = bb::inv(bb::to_monty((uint32_t)N));
+    const uint32_t g = bb::two_adic_generator(n + added);
+    uint32_t base = shift;
+    for (uint32_t j = 0; j < (1u << added); j++) {
+        TwoLevelTable sc;
+        if ((rc = cx.get_scale_table(base, n, hinv, &sc))) return rc;
+        a.sc_lo[j] = sc.lo; a.sc_hi[j] = sc.hi; a.sc_T = sc.T;
+        a.sc_phi[j] = bb::pow(base, 1ull << (n1 + n2 - 4));
+        base = bb::mul(base, g);
+    }
+    tiles = (uint32_t)(((1ull << n1) * wslots) / narrow::NQ);
+    a.xcd_remap = tiles % 32 == 0;
+    if ((rc = launch_narrow<2>(stream, a, n2, tiles))) return rc;
+    // K3
+    a.src = dst; a.dst = dst;
+    a.stage_tw = cx.tile_tw[0];
+    a.xcd_remap = 0;
+    tiles = (uint32_t)((((1ull << added) << n2) * wslots) / narrow::NQ);
+    return launch_narrow<3>(stream, a, n1, tiles);
+}
+
 }  // namespace
 
 int ntt_dft(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* dst, uint64_t height,
@@ -868,6 +949,11 @@ int ntt_coset_lde(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t
     if (m > bb::TWO_ADICITY) return fail(ERR_BAD_ARG, "LDE height exceeds BabyBear two-adicity");
     if (src == dst) return fail(ERR_BAD_ARG, "coset_lde: in-place not supported");
     size_t bytes = height * width * 4;
+    // Narrow matrices (the fib_air trace / quotient): two digits per direction, three launches.
+    {
+        int rcn = lde_narrow(cx, stream, src, dst, n, added_bits, width, shift, bit_reversed_out);
+        if (rcn != 1) return rcn;
+    }
     // Fused plan (three-pass shapes whose digits line up): inverse passes 1..2, fused middle, forward passes 2..3.
     {
         int rcf = lde_fused(cx, stream, src, dst, n, added_bits, width, shift, bit_reversed_out);

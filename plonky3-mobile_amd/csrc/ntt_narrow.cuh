@@ -1,0 +1,243 @@
+// Three-launch coset LDE for NARROW matrices (W = 2, 4 or 8 columns: the fib_air trace and quotient shapes).
+//
+// The general plans (ntt.hip / ntt_fast.cuh) move one 32-bit word per lane and cut 2^n rows into three 6-8 stage
+// digits per direction: five launches for 2^20 -> 2^21, every one re-reading and re-writing the matrix.  Here the
+// height is cut into TWO digits (n = n1 + n2, 8..12 stages each), a lane moves a PAIR of columns (8-byte
+// accesses, one twiddle serves both columns) and carries 16 points through radix-16 register rounds:
+//
+//   K1  narrow_inv1_kernel<n1>   x[r1*N2 + r2]  --DIF over r1, twiddle w^-(r2*k1)-->  T[r2*N1 + k1]   (transposed)
+//   K2  narrow_mid_kernel<n2>    T[r2*N1 + k1]  --DIF over r2--> c[k1 + N1*k2]  (coefficients stay on chip), then for
+//                                every coset j < 2^added of the LDE domain: scale by (shift g^j)^k / N, DIF over k2,
+//                                twiddle w^(k1*m1), store at  rev(j)*N + rev(m1)*N1 + k1
+//   K3  narrow_fwd2_kernel<n1>   contiguous blocks of N1 rows, DIF over k1, in place
+//
+// The LDE over shift*<g> (g of order 2^added * N) in bit-reversed row order is exactly 2^added size-N coset
+// transforms laid side by side (row rev(j)*N + rev_n(m) = evaluation at shift * g^j * w_N^m), so no stage ever
+// runs over the zero padding.  Traffic: (1+1) + (1+2^a) + (2^a+2^a) matrix sweeps = 72 MB for the 2^20 x 2 trace
+// at blowup 2 (was 127 MB), 25 MB algorithmic.
+//
+// LDS tile: [2^B points][4 slots] of uint2, point index XOR-swizzled (sig) so that each of the three register
+// layouts and the bit-reversed hand-over are bank-conflict free for ds_read/write_b64.  Stage twiddles come
+// straight from a 2^12-word table in global memory (L2-resident; uniform addresses in the last round become
+// scalar loads): no LDS table, no barrier before the first butterfly.
+// Included by ntt.hip (needs two_level, rev_bits, power_ladder, crev).
+#pragma once
+
+namespace p3 {
+
+struct NarrowArgs {
+    const uint32_t* src;
+    uint32_t* dst;
+    uint32_t n, n1, n2, W, wsl;   // wsl = log2(W / 2): 8-byte slots per row
+    uint32_t added;
+    const uint32_t* stage_tw;     // this kernel's direction: stage u at offset 2^u - 1 (reference layout, 12 stages)
+    const uint32_t* stage_tw_fwd; // K2: forward table
+    const uint32_t* tw_lo;        // inter-digit twiddles w_N^(+-e), two-level
+    const uint32_t* tw_hi;
+    uint32_t tw_T;
+    const uint32_t* twf_lo;       // K2: forward inter-digit twiddles
+    const uint32_t* twf_hi;
+    uint32_t twf_T;
+    const uint32_t* sc_lo[8];     // K2: per coset j, value(k) = (shift g^j)^k / N
+    const uint32_t* sc_hi[8];
+    uint32_t sc_T;
+    uint32_t sc_phi[8];           // (shift g^j)^(N1 * 2^(n2-4))
+    uint32_t xcd_remap;           // 1: tile count is a multiple of 32, spread groups of 4 adjacent tiles per XCD
+};
+
+namespace narrow {
+
+constexpr uint32_t NQ = 4;  // uint2 slots per tile row
+
+__device__ __forceinline__ uint2 add2(uint2 a, uint2 b) { return make_uint2(bb::add(a.x, b.x), bb::add(a.y, b.y)); }
+__device__ __forceinline__ uint2 sub2(uint2 a, uint2 b) { return make_uint2(bb::sub(a.x, b.x), bb::sub(a.y, b.y)); }
+// a - b + P in (0, 2P): a valid (unreduced) operand of the Montgomery product
+__device__ __forceinline__ uint2 subl2(uint2 a, uint2 b) { return make_uint2(a.x - b.x + bb::P, a.y - b.y + bb::P); }
+__device__ __forceinline__ uint2 mul2(uint2 a, uint32_t w) { return make_uint2(bb::mul(a.x, w), bb::mul(a.y, w)); }
+
+// point held in register j of thread t when the 4-bit register window sits at bit A
+template <int A>
+__device__ __forceinline__ uint32_t pt_of(uint32_t t, uint32_t j) {
+    return ((t >> A) << (A + 4)) | (j << A) | (t & ((1u << A) - 1u));
+}
+__device__ __forceinline__ uint32_t sig(uint32_t pt) { return pt ^ ((pt >> 4) & 7u); }
+
+// DIF stages UHI-1 .. ULO on the registers (window at bit A); stage u pairs points differing in bit u:
+// (a, b) -> (a + b, (a - b) * w_{2^(u+1)}^(pt mod 2^u))   [stage semantics of backend_vulkan.rs:881-942, DIF form]
+template <int A, int UHI, int ULO>
+__device__ __forceinline__ void stage_block(uint2 (&v)[16], const uint32_t* __restrict__ tw, uint32_t t) {
+    const uint32_t tlo = t & ((1u << A) - 1u);
+#pragma unroll
+    for (int u = UHI - 1; u >= ULO; --u) {
+        const int d = u - A;
+        uint32_t w[8];
+        if (u > 0) {
+#pragma unroll
+            for (int jl = 0; jl < 8; jl++)
+                if (jl < (1 << d)) w[jl] = tw[(1u << u) - 1u + (tlo | ((uint32_t)jl << A))];
+        }
+#pragma unroll
+        for (int j0 = 0; j0 < 16; j0++) {
+            if ((j0 >> d) & 1) continue;
+            const int j1 = j0 | (1 << d);
+            const uint2 x = v[j0], y = v[j1];
+            v[j0] = add2(x, y);
+            if (u == 0) v[j1] = sub2(x, y);
+            else v[j1] = mul2(subl2(x, y), w[j0 & ((1 << d) - 1)]);
+        }
+    }
+}
+
+// registers (window AF) -> LDS -> registers (window AT)
+template <int AF, int AT>
+__device__ __forceinline__ void exchange(uint2* tile, uint2 (&v)[16], uint32_t t, uint32_t q) {
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) tile[sig(pt_of<AF>(t, j)) * NQ + q] = v[j];
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) v[j] = tile[sig(pt_of<AT>(t, j)) * NQ + q];
+}
+
+// B-stage DIF of the tile: in: v[j] = point pt_of<B-4>(t, j) (natural order); out: v[j] = position pt_of<0>(t, j),
+// which holds frequency rev_B(position).
+template <int B>
+__device__ __forceinline__ void dif_rounds(uint2 (&v)[16], uint2* tile, const uint32_t* __restrict__ tw, uint32_t t, uint32_t q) {
+    constexpr int A1 = B - 4, A2 = B > 8 ? B - 8 : 0;
+    stage_block<A1, B, A1>(v, tw, t);
+    exchange<A1, A2>(tile, v, t, q);
+    stage_block<A2, A1, A2>(v, tw, t);
+    if constexpr (B > 8) {
+        exchange<A2, 0>(tile, v, t, q);
+        stage_block<0, A2, 0>(v, tw, t);
+    }
+}
+
+// registers in final layout (position pt_of<0>) -> LDS row = frequency rev_B(position) -> registers in the first
+// layout (row pt_of<B-4>): natural frequency order, 16 consecutive rows per 16 lanes.
+template <int B>
+__device__ __forceinline__ void to_natural(uint2* tile, uint2 (&v)[16], uint32_t t, uint32_t q) {
+    __syncthreads();
+    const uint32_t rt = rev_bits(t, B - 4);
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) tile[sig((crev(j, 4) << (B - 4)) | rt) * NQ + q] = v[j];
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) v[j] = tile[sig(pt_of<B - 4>(t, j)) * NQ + q];
+}
+// same hand-over without the bit reversal (K3: position order is already the wanted order)
+template <int B>
+__device__ __forceinline__ void to_rows(uint2* tile, uint2 (&v)[16], uint32_t t, uint32_t q) {
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) tile[sig(pt_of<0>(t, j)) * NQ + q] = v[j];
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) v[j] = tile[sig(pt_of<B - 4>(t, j)) * NQ + q];
+}
+
+// Four adjacent tiles share 128-byte lines of the strided side: keep them on one XCD (workgroups are dealt to
+// the 8 XCDs round-robin by blockIdx) so the line is fetched into one L2 only.
+__device__ __forceinline__ uint32_t tile_of_block(uint32_t bid, uint32_t remap) {
+    if (!remap) return bid;
+    const uint32_t xcd = bid & 7u, s = bid >> 3;
+    return ((s >> 2) << 5) | (xcd << 2) | (s & 3u);
+}
+
+// v[j] *= c * phi^(idx(j)), idx(j) = REV ? rev4(j) : j
+template <bool REV>
+__device__ __forceinline__ void scale_ladder(uint2 (&v)[16], uint32_t c, uint32_t phi) {
+    uint32_t pw[16];
+    power_ladder<16>(c, phi, pw);
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) v[j] = mul2(v[j], pw[REV ? crev(j, 4) : j]);
+}
+
+}  // namespace narrow
+
+// K1: first inverse digit (the high n1 bits of the row index), transposed store.
+template <int B>
+__global__ void __launch_bounds__(1 << (B - 2)) narrow_inv1_kernel(NarrowArgs a) {
+    using namespace narrow;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint2* tile = reinterpret_cast<uint2*>(smem);
+    const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> 2;
+    const uint32_t s = tile_of_block(blockIdx.x, a.xcd_remap) * NQ + q;  // 8-byte slot within a row group of N2 rows
+    const uint32_t lo = s >> a.wsl, cp = s & ((1u << a.wsl) - 1u);
+    const uint64_t rowstride = ((uint64_t)a.W << a.n2);                   // words between r1 and r1 + 1
+    const uint32_t* p = a.src + 2ull * s;
+    uint2 v[16];
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) v[j] = *reinterpret_cast<const uint2*>(p + (uint64_t)pt_of<B - 4>(t, j) * rowstride);
+    dif_rounds<B>(v, tile, a.stage_tw, t, q);
+    // position (t << 4) | j holds k1 = rev_B(position) = (rev4(j) << (B-4)) | rev(t): twiddle w^-(lo * k1)
+    {
+        const uint32_t c = two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)lo * rev_bits(t, B - 4));
+        const uint32_t phi = two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)lo << (B - 4));
+        scale_ladder<true>(v, c, phi);
+    }
+    to_natural<B>(tile, v, t, q);
+    // T[(lo * N1 + k1) * W + 2 cp], k1 = pt_of<B-4>(t, j): 16 lanes x 8 bytes contiguous per (lo, cp)
+    uint32_t* o = a.dst + (((uint64_t)lo << B) * a.W + 2u * cp);
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) *reinterpret_cast<uint2*>(o + (uint64_t)pt_of<B - 4>(t, j) * a.W) = v[j];
+}
+
+// K2: second inverse digit, then per coset: scale, first forward digit, twiddle, strided store.
+template <int B>
+__global__ void __launch_bounds__(1 << (B - 2)) narrow_mid_kernel(NarrowArgs a) {
+    using namespace narrow;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint2* tile = reinterpret_cast<uint2*>(smem);
+    const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> 2;
+    const uint32_t s = tile_of_block(blockIdx.x, a.xcd_remap) * NQ + q;  // slot within a group of N1 rows
+    const uint32_t k1 = s >> a.wsl;
+    const uint64_t rowstride = ((uint64_t)a.W << a.n1);
+    const uint32_t* p = a.src + 2ull * s;
+    uint2 c[16];
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) c[j] = *reinterpret_cast<const uint2*>(p + (uint64_t)pt_of<B - 4>(t, j) * rowstride);
+    dif_rounds<B>(c, tile, a.stage_tw, t, q);
+    to_natural<B>(tile, c, t, q);  // c[j] = coefficient k = k1 + N1 * k2, k2 = pt_of<B-4>(t, j) = (j << (B-4)) | t
+    // forward twiddle w^(k1 * m1), m1 = rev_B(position): the same for every coset
+    uint32_t pw2[16];
+    {
+        const uint32_t c0 = two_level(a.twf_lo, a.twf_hi, a.twf_T, (uint64_t)k1 * rev_bits(t, B - 4));
+        const uint32_t phi = two_level(a.twf_lo, a.twf_hi, a.twf_T, (uint64_t)k1 << (B - 4));
+        power_ladder<16>(c0, phi, pw2);
+    }
+    const uint64_t kbase = (uint64_t)k1 + ((uint64_t)t << a.n1);
+    const uint32_t ncos = 1u << a.added;
+    for (uint32_t jc = 0; jc < ncos; jc++) {
+        uint2 v[16];
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) v[j] = c[j];
+        scale_ladder<false>(v, two_level(a.sc_lo[jc], a.sc_hi[jc], a.sc_T, kbase), a.sc_phi[jc]);
+        dif_rounds<B>(v, tile, a.stage_tw_fwd, t, q);
+        uint32_t* o = a.dst + (((uint64_t)rev_bits(jc, a.added) << a.n) * a.W + 2ull * s);
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++)
+            *reinterpret_cast<uint2*>(o + (uint64_t)pt_of<0>(t, j) * rowstride) = mul2(v[j], pw2[crev(j, 4)]);
+    }
+}
+
+// K3: last forward digit on contiguous blocks of 2^B rows, in place.
+template <int B>
+__global__ void __launch_bounds__(1 << (B - 2)) narrow_fwd2_kernel(NarrowArgs a) {
+    using namespace narrow;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint2* tile = reinterpret_cast<uint2*>(smem);
+    const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> 2;
+    const uint32_t s = blockIdx.x * NQ + q;
+    const uint32_t blk = s >> a.wsl, cp = s & ((1u << a.wsl) - 1u);
+    uint32_t* p = a.dst + (((uint64_t)blk << B) * a.W + 2u * cp);
+    uint2 v[16];
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) v[j] = *reinterpret_cast<const uint2*>(p + (uint64_t)pt_of<B - 4>(t, j) * a.W);
+    dif_rounds<B>(v, tile, a.stage_tw, t, q);
+    to_rows<B>(tile, v, t, q);
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) *reinterpret_cast<uint2*>(p + (uint64_t)pt_of<B - 4>(t, j) * a.W) = v[j];
+}
+
+}  // namespace p3

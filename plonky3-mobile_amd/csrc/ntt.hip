@@ -821,10 +821,14 @@ int lde_fused(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* ds
 }
 
 
-template <int B, int K>
+template <int B, int LQ, int K>
 int launch_narrow_t(hipStream_t stream, const NarrowArgs& a, uint32_t blocks) {
-    constexpr size_t lds = ((size_t)1 << B) * narrow::NQ * 8;
-    auto kern = K == 1 ? narrow_inv1_kernel<B> : (K == 2 ? narrow_mid_kernel<B> : narrow_fwd2_kernel<B>);
+    // tile + stage-table copies (K2: inverse prefix + whole forward table)
+    constexpr size_t lds = ((size_t)8 << (B + LQ)) + ((size_t)4 << (B - 4)) + (K == 2 ? ((size_t)4 << B) : 0);
+    void (*kern)(NarrowArgs);
+    if constexpr (K == 1) kern = narrow_inv1_kernel<B, LQ>;
+    else if constexpr (K == 2) kern = narrow_mid_kernel<B, LQ>;
+    else kern = narrow_fwd2_kernel<B, LQ>;
     if constexpr (lds > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -832,18 +836,21 @@ int launch_narrow_t(hipStream_t stream, const NarrowArgs& a, uint32_t blocks) {
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(1u << (B - 2)), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(1u << (B - 4 + LQ)), lds, stream, a);
     P3_HIP(hipGetLastError());
     return OK;
 }
+// slots per tile: 4 (32-byte row segments), 2 for 12-stage tiles: 64 KB of LDS and 512 threads, so that two
+// workgroups share a CU (one loads or stores while the other computes) and the middle kernel keeps 256 VGPRs
+constexpr int narrow_lq(int b, int k) { (void)k; return b == 12 ? 1 : 2; }
 template <int K>
 int launch_narrow(hipStream_t stream, const NarrowArgs& a, uint32_t b, uint32_t blocks) {
     switch (b) {
-        case 8: return launch_narrow_t<8, K>(stream, a, blocks);
-        case 9: return launch_narrow_t<9, K>(stream, a, blocks);
-        case 10: return launch_narrow_t<10, K>(stream, a, blocks);
-        case 11: return launch_narrow_t<11, K>(stream, a, blocks);
-        case 12: return launch_narrow_t<12, K>(stream, a, blocks);
+        case 8: return launch_narrow_t<8, narrow_lq(8, K), K>(stream, a, blocks);
+        case 9: return launch_narrow_t<9, narrow_lq(9, K), K>(stream, a, blocks);
+        case 10: return launch_narrow_t<10, narrow_lq(10, K), K>(stream, a, blocks);
+        case 11: return launch_narrow_t<11, narrow_lq(11, K), K>(stream, a, blocks);
+        case 12: return launch_narrow_t<12, narrow_lq(12, K), K>(stream, a, blocks);
         default: return fail(ERR_INTERNAL, "lde_narrow: digit out of range");
     }
 }
@@ -872,8 +879,8 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     a.src = src; a.dst = T;
     a.stage_tw = cx.tile_tw[1];
     a.tw_lo = ti.lo; a.tw_hi = ti.hi; a.tw_T = ti.T;
-    uint32_t tiles = (uint32_t)(((1ull << n2) * wslots) / narrow::NQ);
-    a.xcd_remap = tiles % 32 == 0;
+    uint32_t tiles = (uint32_t)(((1ull << n2) * wslots) >> narrow_lq(n1, 1));
+    a.xcd_remap = tiles % 64 == 0;
     if ((rc = launch_narrow<1>(stream, a, n1, tiles))) return rc;
     // K2
     a.src = T; a.dst = dst;
@@ -889,14 +896,14 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
         a.sc_phi[j] = bb::pow(base, 1ull << (n1 + n2 - 4));
         base = bb::mul(base, g);
     }
-    tiles = (uint32_t)(((1ull << n1) * wslots) / narrow::NQ);
-    a.xcd_remap = tiles % 32 == 0;
+    tiles = (uint32_t)(((1ull << n1) * wslots) >> narrow_lq(n2, 2));
+    a.xcd_remap = tiles % 64 == 0;
     if ((rc = launch_narrow<2>(stream, a, n2, tiles))) return rc;
     // K3
     a.src = dst; a.dst = dst;
     a.stage_tw = cx.tile_tw[0];
     a.xcd_remap = 0;
-    tiles = (uint32_t)((((1ull << added) << n2) * wslots) / narrow::NQ);
+    tiles = (uint32_t)((((1ull << added) << n2) * wslots) >> narrow_lq(n1, 3));
     return launch_narrow<3>(stream, a, n1, tiles);
 }
 

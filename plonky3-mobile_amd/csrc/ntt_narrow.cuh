@@ -16,10 +16,10 @@
 // runs over the zero padding.  Traffic: (1+1) + (1+2^a) + (2^a+2^a) matrix sweeps = 72 MB for the 2^20 x 2 trace
 // at blowup 2 (was 127 MB), 25 MB algorithmic.
 //
-// LDS tile: [2^B points][4 slots] of uint2, point index XOR-swizzled (sig) so that each of the three register
-// layouts and the bit-reversed hand-over are bank-conflict free for ds_read/write_b64.  Stage twiddles come
-// straight from a 2^12-word table in global memory (L2-resident; uniform addresses in the last round become
-// scalar loads): no LDS table, no barrier before the first butterfly.
+// LDS tile: [2^B points][2^LQ slots] of uint2 (LQ = 2: 32-byte row segments; 1 for the 12-stage middle kernel), point index XOR-swizzled (sig) so that each of the three register
+// layouts and the bit-reversed hand-over are bank-conflict free for ds_read/write_b64.  The first round's 15 stage twiddles per
+// lane are fetched from the global table at kernel entry, beside the data loads; the later rounds read a small
+// LDS copy that is complete by the first exchange: no barrier precedes the first butterfly.
 // Included by ntt.hip (needs two_level, rev_bits, power_ladder, crev).
 #pragma once
 
@@ -47,7 +47,6 @@ struct NarrowArgs {
 
 namespace narrow {
 
-constexpr uint32_t NQ = 4;  // uint2 slots per tile row
 
 __device__ __forceinline__ uint2 add2(uint2 a, uint2 b) { return make_uint2(bb::add(a.x, b.x), bb::add(a.y, b.y)); }
 __device__ __forceinline__ uint2 sub2(uint2 a, uint2 b) { return make_uint2(bb::sub(a.x, b.x), bb::sub(a.y, b.y)); }
@@ -60,7 +59,11 @@ template <int A>
 __device__ __forceinline__ uint32_t pt_of(uint32_t t, uint32_t j) {
     return ((t >> A) << (A + 4)) | (j << A) | (t & ((1u << A) - 1u));
 }
-__device__ __forceinline__ uint32_t sig(uint32_t pt) { return pt ^ ((pt >> 4) & 7u); }
+// XOR swizzle of the point index: a half-wave (32 lanes x 8 bytes = all 64 banks) covers 32 / NQ tile rows, which must
+// differ in their low log2(32 / NQ) bits for each register layout (windows at bit B-4, B-8, 0: the lanes' fastest
+// point bits are bits 0.., bits 0..A-1 then A+4.., and bits 4.. respectively).
+template <int LQ>
+__device__ __forceinline__ uint32_t sig(uint32_t pt) { return pt ^ ((pt >> 4) & ((32u >> LQ) - 1u)); }
 
 // DIF stages UHI-1 .. ULO on the registers (window at bit A); stage u pairs points differing in bit u:
 // (a, b) -> (a + b, (a - b) * w_{2^(u+1)}^(pt mod 2^u))   [stage semantics of backend_vulkan.rs:881-942, DIF form]
@@ -88,60 +91,95 @@ __device__ __forceinline__ void stage_block(uint2 (&v)[16], const uint32_t* __re
     }
 }
 
+// Round 1 (window at bit B-4, stages B-1 .. B-4) with its 15 twiddles already in registers: they are fetched from
+// the global table at kernel entry, next to the data loads, so no butterfly ever waits for an L2 round trip.
+template <int B>
+__device__ __forceinline__ void load_round1_twiddles(const uint32_t* __restrict__ tw, uint32_t t, uint32_t (&w1)[15]) {
+#pragma unroll
+    for (int d = 0; d < 4; d++)
+#pragma unroll
+        for (int jl = 0; jl < (1 << d); jl++) w1[(1 << d) - 1 + jl] = tw[(1u << (B - 4 + d)) - 1u + (t | ((uint32_t)jl << (B - 4)))];
+}
+__device__ __forceinline__ void stage_block_round1(uint2 (&v)[16], const uint32_t (&w1)[15]) {
+#pragma unroll
+    for (int d = 3; d >= 0; --d) {
+#pragma unroll
+        for (int j0 = 0; j0 < 16; j0++) {
+            if ((j0 >> d) & 1) continue;
+            const int j1 = j0 | (1 << d);
+            const uint2 x = v[j0], y = v[j1];
+            v[j0] = add2(x, y);
+            v[j1] = mul2(subl2(x, y), w1[(1 << d) - 1 + (j0 & ((1 << d) - 1))]);
+        }
+    }
+}
+
 // registers (window AF) -> LDS -> registers (window AT)
-template <int AF, int AT>
+template <int LQ, int AF, int AT>
 __device__ __forceinline__ void exchange(uint2* tile, uint2 (&v)[16], uint32_t t, uint32_t q) {
     __syncthreads();
 #pragma unroll
-    for (uint32_t j = 0; j < 16; j++) tile[sig(pt_of<AF>(t, j)) * NQ + q] = v[j];
+    for (uint32_t j = 0; j < 16; j++) tile[(sig<LQ>(pt_of<AF>(t, j)) << LQ) + q] = v[j];
     __syncthreads();
 #pragma unroll
-    for (uint32_t j = 0; j < 16; j++) v[j] = tile[sig(pt_of<AT>(t, j)) * NQ + q];
+    for (uint32_t j = 0; j < 16; j++) v[j] = tile[(sig<LQ>(pt_of<AT>(t, j)) << LQ) + q];
 }
 
 // B-stage DIF of the tile: in: v[j] = point pt_of<B-4>(t, j) (natural order); out: v[j] = position pt_of<0>(t, j),
-// which holds frequency rev_B(position).
-template <int B>
-__device__ __forceinline__ void dif_rounds(uint2 (&v)[16], uint2* tile, const uint32_t* __restrict__ tw, uint32_t t, uint32_t q) {
+// which holds frequency rev_B(position).  twl: stage table in LDS (stages below B-4 at least).
+template <int B, int LQ>
+__device__ __forceinline__ void dif_rounds_after1(uint2 (&v)[16], uint2* tile, const uint32_t* twl, uint32_t t, uint32_t q) {
     constexpr int A1 = B - 4, A2 = B > 8 ? B - 8 : 0;
-    stage_block<A1, B, A1>(v, tw, t);
-    exchange<A1, A2>(tile, v, t, q);
-    stage_block<A2, A1, A2>(v, tw, t);
+    exchange<LQ, A1, A2>(tile, v, t, q);
+    stage_block<A2, A1, A2>(v, twl, t);
     if constexpr (B > 8) {
-        exchange<A2, 0>(tile, v, t, q);
-        stage_block<0, A2, 0>(v, tw, t);
+        exchange<LQ, A2, 0>(tile, v, t, q);
+        stage_block<0, A2, 0>(v, twl, t);
     }
+}
+template <int B, int LQ>
+__device__ __forceinline__ void dif_rounds(uint2 (&v)[16], uint2* tile, const uint32_t (&w1)[15], const uint32_t* twl, uint32_t t, uint32_t q) {
+    stage_block_round1(v, w1);
+    dif_rounds_after1<B, LQ>(v, tile, twl, t, q);
+}
+// round 1 from a full table in LDS as well (K2's forward transforms)
+template <int B, int LQ>
+__device__ __forceinline__ void dif_rounds_lds(uint2 (&v)[16], uint2* tile, const uint32_t* twl, uint32_t t, uint32_t q) {
+    stage_block<B - 4, B, B - 4>(v, twl, t);
+    dif_rounds_after1<B, LQ>(v, tile, twl, t, q);
 }
 
 // registers in final layout (position pt_of<0>) -> LDS row = frequency rev_B(position) -> registers in the first
 // layout (row pt_of<B-4>): natural frequency order, 16 consecutive rows per 16 lanes.
-template <int B>
+template <int B, int LQ>
 __device__ __forceinline__ void to_natural(uint2* tile, uint2 (&v)[16], uint32_t t, uint32_t q) {
     __syncthreads();
     const uint32_t rt = rev_bits(t, B - 4);
 #pragma unroll
-    for (uint32_t j = 0; j < 16; j++) tile[sig((crev(j, 4) << (B - 4)) | rt) * NQ + q] = v[j];
+    for (uint32_t j = 0; j < 16; j++) tile[(sig<LQ>((crev(j, 4) << (B - 4)) | rt) << LQ) + q] = v[j];
     __syncthreads();
 #pragma unroll
-    for (uint32_t j = 0; j < 16; j++) v[j] = tile[sig(pt_of<B - 4>(t, j)) * NQ + q];
+    for (uint32_t j = 0; j < 16; j++) v[j] = tile[(sig<LQ>(pt_of<B - 4>(t, j)) << LQ) + q];
 }
 // same hand-over without the bit reversal (K3: position order is already the wanted order)
-template <int B>
+template <int B, int LQ>
 __device__ __forceinline__ void to_rows(uint2* tile, uint2 (&v)[16], uint32_t t, uint32_t q) {
     __syncthreads();
 #pragma unroll
-    for (uint32_t j = 0; j < 16; j++) tile[sig(pt_of<0>(t, j)) * NQ + q] = v[j];
+    for (uint32_t j = 0; j < 16; j++) tile[(sig<LQ>(pt_of<0>(t, j)) << LQ) + q] = v[j];
     __syncthreads();
 #pragma unroll
-    for (uint32_t j = 0; j < 16; j++) v[j] = tile[sig(pt_of<B - 4>(t, j)) * NQ + q];
+    for (uint32_t j = 0; j < 16; j++) v[j] = tile[(sig<LQ>(pt_of<B - 4>(t, j)) << LQ) + q];
 }
 
-// Four adjacent tiles share 128-byte lines of the strided side: keep them on one XCD (workgroups are dealt to
+// Adjacent tiles (four of them for 32-byte segments) share 128-byte lines of the strided side: keep them on one XCD (workgroups are dealt to
 // the 8 XCDs round-robin by blockIdx) so the line is fetched into one L2 only.
+template <int LQ>
 __device__ __forceinline__ uint32_t tile_of_block(uint32_t bid, uint32_t remap) {
     if (!remap) return bid;
+    constexpr uint32_t LG = 4 - LQ;  // log2(tiles per 128-byte line)
     const uint32_t xcd = bid & 7u, s = bid >> 3;
-    return ((s >> 2) << 5) | (xcd << 2) | (s & 3u);
+    return ((s >> LG) << (LG + 3)) | (xcd << LG) | (s & ((1u << LG) - 1u));
 }
 
 // v[j] *= c * phi^(idx(j)), idx(j) = REV ? rev4(j) : j
@@ -156,27 +194,30 @@ __device__ __forceinline__ void scale_ladder(uint2 (&v)[16], uint32_t c, uint32_
 }  // namespace narrow
 
 // K1: first inverse digit (the high n1 bits of the row index), transposed store.
-template <int B>
-__global__ void __launch_bounds__(1 << (B - 2)) narrow_inv1_kernel(NarrowArgs a) {
+template <int B, int LQ>
+__global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow_inv1_kernel(NarrowArgs a) {
     using namespace narrow;
+    constexpr uint32_t NQ = 1u << LQ, NTH = 1u << (B - 4 + LQ);
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint2* tile = reinterpret_cast<uint2*>(smem);
-    const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> 2;
-    const uint32_t s = tile_of_block(blockIdx.x, a.xcd_remap) * NQ + q;  // 8-byte slot within a row group of N2 rows
+    uint32_t* twl = smem + (2u << (B + LQ));                                // stages below B-4: 2^(B-4) - 1 words
+    const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> LQ;
+    const uint32_t s = tile_of_block<LQ>(blockIdx.x, a.xcd_remap) * NQ + q;  // 8-byte slot within a row group of N2 rows
     const uint32_t lo = s >> a.wsl, cp = s & ((1u << a.wsl) - 1u);
     const uint64_t rowstride = ((uint64_t)a.W << a.n2);                   // words between r1 and r1 + 1
     const uint32_t* p = a.src + 2ull * s;
     uint2 v[16];
 #pragma unroll
     for (uint32_t j = 0; j < 16; j++) v[j] = *reinterpret_cast<const uint2*>(p + (uint64_t)pt_of<B - 4>(t, j) * rowstride);
-    dif_rounds<B>(v, tile, a.stage_tw, t, q);
+    uint32_t w1[15];
+    load_round1_twiddles<B>(a.stage_tw, t, w1);
+    for (uint32_t i = threadIdx.x; i + 1 < (1u << (B - 4)); i += NTH) twl[i] = a.stage_tw[i];
     // position (t << 4) | j holds k1 = rev_B(position) = (rev4(j) << (B-4)) | rev(t): twiddle w^-(lo * k1)
-    {
-        const uint32_t c = two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)lo * rev_bits(t, B - 4));
-        const uint32_t phi = two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)lo << (B - 4));
-        scale_ladder<true>(v, c, phi);
-    }
-    to_natural<B>(tile, v, t, q);
+    const uint32_t c = two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)lo * rev_bits(t, B - 4));
+    const uint32_t phi = two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)lo << (B - 4));
+    dif_rounds<B, LQ>(v, tile, w1, twl, t, q);
+    scale_ladder<true>(v, c, phi);
+    to_natural<B, LQ>(tile, v, t, q);
     // T[(lo * N1 + k1) * W + 2 cp], k1 = pt_of<B-4>(t, j): 16 lanes x 8 bytes contiguous per (lo, cp)
     uint32_t* o = a.dst + (((uint64_t)lo << B) * a.W + 2u * cp);
 #pragma unroll
@@ -184,58 +225,80 @@ __global__ void __launch_bounds__(1 << (B - 2)) narrow_inv1_kernel(NarrowArgs a)
 }
 
 // K2: second inverse digit, then per coset: scale, first forward digit, twiddle, strided store.
-template <int B>
-__global__ void __launch_bounds__(1 << (B - 2)) narrow_mid_kernel(NarrowArgs a) {
+template <int B, int LQ>
+__global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow_mid_kernel(NarrowArgs a) {
     using namespace narrow;
+    constexpr uint32_t NQ = 1u << LQ, NTH = 1u << (B - 4 + LQ);
+    constexpr bool LEAN = NTH >= 1024;  // 128 VGPRs per lane: rebuild the output ladder per coset
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint2* tile = reinterpret_cast<uint2*>(smem);
-    const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> 2;
-    const uint32_t s = tile_of_block(blockIdx.x, a.xcd_remap) * NQ + q;  // slot within a group of N1 rows
+    uint32_t* twl_i = smem + (2u << (B + LQ));   // inverse stages below B-4
+    uint32_t* twl_f = twl_i + (1u << (B - 4)); // forward table, all B stages
+    const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> LQ;
+    const uint32_t s = tile_of_block<LQ>(blockIdx.x, a.xcd_remap) * NQ + q;  // slot within a group of N1 rows
     const uint32_t k1 = s >> a.wsl;
     const uint64_t rowstride = ((uint64_t)a.W << a.n1);
     const uint32_t* p = a.src + 2ull * s;
     uint2 c[16];
 #pragma unroll
     for (uint32_t j = 0; j < 16; j++) c[j] = *reinterpret_cast<const uint2*>(p + (uint64_t)pt_of<B - 4>(t, j) * rowstride);
-    dif_rounds<B>(c, tile, a.stage_tw, t, q);
-    to_natural<B>(tile, c, t, q);  // c[j] = coefficient k = k1 + N1 * k2, k2 = pt_of<B-4>(t, j) = (j << (B-4)) | t
-    // forward twiddle w^(k1 * m1), m1 = rev_B(position): the same for every coset
-    uint32_t pw2[16];
     {
-        const uint32_t c0 = two_level(a.twf_lo, a.twf_hi, a.twf_T, (uint64_t)k1 * rev_bits(t, B - 4));
-        const uint32_t phi = two_level(a.twf_lo, a.twf_hi, a.twf_T, (uint64_t)k1 << (B - 4));
-        power_ladder<16>(c0, phi, pw2);
+        uint32_t w1[15];
+        load_round1_twiddles<B>(a.stage_tw, t, w1);
+        for (uint32_t i = threadIdx.x; i + 1 < (1u << (B - 4)); i += NTH) twl_i[i] = a.stage_tw[i];
+        for (uint32_t i = threadIdx.x; i + 1 < (1u << B); i += NTH) twl_f[i] = a.stage_tw_fwd[i];
+        dif_rounds<B, LQ>(c, tile, w1, twl_i, t, q);
     }
+    // forward twiddle w^(k1 * m1), m1 = rev_B(position): the same for every coset
+    const uint32_t c0 = two_level(a.twf_lo, a.twf_hi, a.twf_T, (uint64_t)k1 * rev_bits(t, B - 4));
+    const uint32_t phi0 = two_level(a.twf_lo, a.twf_hi, a.twf_T, (uint64_t)k1 << (B - 4));
     const uint64_t kbase = (uint64_t)k1 + ((uint64_t)t << a.n1);
+    uint32_t sc_next = two_level(a.sc_lo[0], a.sc_hi[0], a.sc_T, kbase);
+    to_natural<B, LQ>(tile, c, t, q);  // c[j] = coefficient k = k1 + N1 * k2, k2 = pt_of<B-4>(t, j) = (j << (B-4)) | t
+    uint32_t pw2[LEAN ? 1 : 16];
+    if constexpr (!LEAN) power_ladder<16>(c0, phi0, pw2);
     const uint32_t ncos = 1u << a.added;
     for (uint32_t jc = 0; jc < ncos; jc++) {
+        const uint32_t sc = sc_next;
+        if (jc + 1 < ncos) sc_next = two_level(a.sc_lo[jc + 1], a.sc_hi[jc + 1], a.sc_T, kbase);
         uint2 v[16];
 #pragma unroll
         for (uint32_t j = 0; j < 16; j++) v[j] = c[j];
-        scale_ladder<false>(v, two_level(a.sc_lo[jc], a.sc_hi[jc], a.sc_T, kbase), a.sc_phi[jc]);
-        dif_rounds<B>(v, tile, a.stage_tw_fwd, t, q);
+        scale_ladder<false>(v, sc, a.sc_phi[jc]);
+        dif_rounds_lds<B, LQ>(v, tile, twl_f, t, q);
         uint32_t* o = a.dst + (((uint64_t)rev_bits(jc, a.added) << a.n) * a.W + 2ull * s);
+        if constexpr (LEAN) {
+            scale_ladder<true>(v, c0, phi0);
 #pragma unroll
-        for (uint32_t j = 0; j < 16; j++)
-            *reinterpret_cast<uint2*>(o + (uint64_t)pt_of<0>(t, j) * rowstride) = mul2(v[j], pw2[crev(j, 4)]);
+            for (uint32_t j = 0; j < 16; j++) *reinterpret_cast<uint2*>(o + (uint64_t)pt_of<0>(t, j) * rowstride) = v[j];
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < 16; j++)
+                *reinterpret_cast<uint2*>(o + (uint64_t)pt_of<0>(t, j) * rowstride) = mul2(v[j], pw2[crev(j, 4)]);
+        }
     }
 }
 
 // K3: last forward digit on contiguous blocks of 2^B rows, in place.
-template <int B>
-__global__ void __launch_bounds__(1 << (B - 2)) narrow_fwd2_kernel(NarrowArgs a) {
+template <int B, int LQ>
+__global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow_fwd2_kernel(NarrowArgs a) {
     using namespace narrow;
+    constexpr uint32_t NQ = 1u << LQ, NTH = 1u << (B - 4 + LQ);
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint2* tile = reinterpret_cast<uint2*>(smem);
-    const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> 2;
+    uint32_t* twl = smem + (2u << (B + LQ));
+    const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> LQ;
     const uint32_t s = blockIdx.x * NQ + q;
     const uint32_t blk = s >> a.wsl, cp = s & ((1u << a.wsl) - 1u);
     uint32_t* p = a.dst + (((uint64_t)blk << B) * a.W + 2u * cp);
     uint2 v[16];
 #pragma unroll
     for (uint32_t j = 0; j < 16; j++) v[j] = *reinterpret_cast<const uint2*>(p + (uint64_t)pt_of<B - 4>(t, j) * a.W);
-    dif_rounds<B>(v, tile, a.stage_tw, t, q);
-    to_rows<B>(tile, v, t, q);
+    uint32_t w1[15];
+    load_round1_twiddles<B>(a.stage_tw, t, w1);
+    for (uint32_t i = threadIdx.x; i + 1 < (1u << (B - 4)); i += NTH) twl[i] = a.stage_tw[i];
+    dif_rounds<B, LQ>(v, tile, w1, twl, t, q);
+    to_rows<B, LQ>(tile, v, t, q);
 #pragma unroll
     for (uint32_t j = 0; j < 16; j++) *reinterpret_cast<uint2*>(p + (uint64_t)pt_of<B - 4>(t, j) * a.W) = v[j];
 }

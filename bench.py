@@ -150,12 +150,12 @@ def main():
     roof = job.lde_roofline(reps=20)
     traffic, traffic_src = None, None
     try:  # HBM-side bytes of the same LDE unit from the committed PMC passes (not collected live)
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_lde.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_lde_v2.json")) as f:
             pmc = json.load(f)
         key = {(20, 1): "cfg2_lde_2^20x2_blowup2", (24, 2): "cfg3_lde_2^24x2_blowup4"}.get((args.log_height, args.log_blowup))
         if key:
             traffic = pmc[key]["total_bytes"]
-            traffic_src = "profiles/r01_pmc_lde.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, summed over the unit's launches"
+            traffic_src = "profiles/r01_pmc_lde_v2.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, summed over the unit's three launches (tools/pmc_probe.py, tools/pmc_summarize.py)"
     except Exception:
         pass
     out = {
@@ -179,7 +179,7 @@ def main():
                    "parallelism": "independent proofs, instance i -> rank i mod N; RCCL only scatters descriptors / gathers proof bytes"},
         "roofline": {"bound": "hbm", "achieved": roof["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": roof["gbps"] / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "coset_lde_batch (ntt_pass_kernel launches)", "algorithmic_bytes": roof["bytes"],
+                     "kernel": "coset_lde_batch = narrow_inv1_kernel + narrow_mid_kernel + narrow_fwd2_kernel (one unit, three launches)", "algorithmic_bytes": roof["bytes"],
                      "avg_us": roof["avg_us"], "batched_gbps": roof.get("batched_gbps")},
         # The kernel that dominates a proof BY TIME is Poseidon2 (12.6 M permutations per 2^20 proof, ~80 % of the GPU
         # time) and it is integer-VALU-bound, which the contract's hbm|mfma roofline cannot express: reported here

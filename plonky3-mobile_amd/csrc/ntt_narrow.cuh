@@ -16,13 +16,19 @@
 // runs over the zero padding.  Traffic: (1+1) + (1+2^a) + (2^a+2^a) matrix sweeps = 72 MB for the 2^20 x 2 trace
 // at blowup 2 (was 127 MB), 25 MB algorithmic.
 //
-// LDS tile: [2^B points][2^LQ slots] of uint2 (LQ = 2: 32-byte row segments; 1 for the 12-stage middle kernel), point index XOR-swizzled (sig) so that each of the three register
-// layouts and the bit-reversed hand-over are bank-conflict free for ds_read/write_b64.  The first round's 15 stage twiddles per
+// LDS tile: [2^B points][2^LQ slots] of uint2 (LQ = 2: 32-byte row segments; 1 for the 12-stage middle kernel), one padding row per 16 so that each of the three register layouts is bank-conflict
+// free for ds_read/write_b64 and a lane's sixteen rows are immediates off one base address.  The first round's 15 stage twiddles per
 // lane are fetched from the global table at kernel entry, beside the data loads; the later rounds read a small
 // LDS copy that is complete by the first exchange: no barrier precedes the first butterfly.
 // Included by ntt.hip (needs two_level, rev_bits, power_ladder, crev).
 #pragma once
 
+// Experiment switch: compile the 512-thread middle kernels for 4 waves per SIMD (128 VGPRs) so that two workgroups
+// share a CU.  Measured slower (the 2^24 middle pass 586 -> 898 us): the ~55 spilled registers cost more than the
+// second workgroup hides.
+#ifndef NARROW_MID_SHARE_CU
+#define NARROW_MID_SHARE_CU 0
+#endif
 namespace p3 {
 
 struct NarrowArgs {
@@ -54,16 +60,26 @@ __device__ __forceinline__ uint2 sub2(uint2 a, uint2 b) { return make_uint2(bb::
 __device__ __forceinline__ uint2 subl2(uint2 a, uint2 b) { return make_uint2(a.x - b.x + bb::P, a.y - b.y + bb::P); }
 __device__ __forceinline__ uint2 mul2(uint2 a, uint32_t w) { return make_uint2(bb::mul(a.x, w), bb::mul(a.y, w)); }
 
-// point held in register j of thread t when the 4-bit register window sits at bit A
+// point held in register j of thread t when the 4-bit register window sits at bit A: pt = T(t) | (j << A)
 template <int A>
 __device__ __forceinline__ uint32_t pt_of(uint32_t t, uint32_t j) {
     return ((t >> A) << (A + 4)) | (j << A) | (t & ((1u << A) - 1u));
 }
-// XOR swizzle of the point index: a half-wave (32 lanes x 8 bytes = all 64 banks) covers 32 / NQ tile rows, which must
-// differ in their low log2(32 / NQ) bits for each register layout (windows at bit B-4, B-8, 0: the lanes' fastest
-// point bits are bits 0.., bits 0..A-1 then A+4.., and bits 4.. respectively).
+// LDS row of a point: one padding row after every 16 (row = pt + (pt >> 4)).  T(t) and j << A occupy disjoint
+// bits, so (T + J) >> 4 = (T >> 4) + (J >> 4) and the row splits into a per-thread base plus a compile-time
+// offset per register: sixteen accesses cost one address VGPR and sixteen immediates.  With the odd stride
+// 17 every register layout is bank-conflict free for ds_read/write_b64: a half-wave (32 lanes x 8 bytes = all
+// 64 banks) covers 32 / NQ consecutive t, whose rows differ in their low log2(32 / NQ) bits (window at bit B-4:
+// consecutive rows; window at 0: rows 17 apart; window at B-8: low bits of t are consecutive rows, the next
+// bits add 4 * 17 per step).
+template <int LQ, int A>
+__device__ __forceinline__ uint32_t lds_base(uint32_t t, uint32_t q) {
+    const uint32_t T = ((t >> A) << (A + 4)) | (t & ((1u << A) - 1u));
+    return ((T + (T >> 4)) << LQ) + q;
+}
 template <int LQ>
-__device__ __forceinline__ uint32_t sig(uint32_t pt) { return pt ^ ((pt >> 4) & ((32u >> LQ) - 1u)); }
+constexpr uint32_t lds_joff(uint32_t J) { return (J + (J >> 4)) << LQ; }
+constexpr uint32_t lds_rows(int B) { return (1u << B) + (1u << (B - 4)); }
 
 // DIF stages UHI-1 .. ULO on the registers (window at bit A); stage u pairs points differing in bit u:
 // (a, b) -> (a + b, (a - b) * w_{2^(u+1)}^(pt mod 2^u))   [stage semantics of backend_vulkan.rs:881-942, DIF form]
@@ -118,11 +134,13 @@ __device__ __forceinline__ void stage_block_round1(uint2 (&v)[16], const uint32_
 template <int LQ, int AF, int AT>
 __device__ __forceinline__ void exchange(uint2* tile, uint2 (&v)[16], uint32_t t, uint32_t q) {
     __syncthreads();
+    uint2* wp = tile + lds_base<LQ, AF>(t, q);
 #pragma unroll
-    for (uint32_t j = 0; j < 16; j++) tile[(sig<LQ>(pt_of<AF>(t, j)) << LQ) + q] = v[j];
+    for (uint32_t j = 0; j < 16; j++) wp[lds_joff<LQ>(j << AF)] = v[j];
     __syncthreads();
+    const uint2* rp = tile + lds_base<LQ, AT>(t, q);
 #pragma unroll
-    for (uint32_t j = 0; j < 16; j++) v[j] = tile[(sig<LQ>(pt_of<AT>(t, j)) << LQ) + q];
+    for (uint32_t j = 0; j < 16; j++) v[j] = rp[lds_joff<LQ>(j << AT)];
 }
 
 // B-stage DIF of the tile: in: v[j] = point pt_of<B-4>(t, j) (natural order); out: v[j] = position pt_of<0>(t, j),
@@ -142,34 +160,24 @@ __device__ __forceinline__ void dif_rounds(uint2 (&v)[16], uint2* tile, const ui
     stage_block_round1(v, w1);
     dif_rounds_after1<B, LQ>(v, tile, twl, t, q);
 }
-// round 1 from a full table in LDS as well (K2's forward transforms)
-template <int B, int LQ>
-__device__ __forceinline__ void dif_rounds_lds(uint2 (&v)[16], uint2* tile, const uint32_t* twl, uint32_t t, uint32_t q) {
-    stage_block<B - 4, B, B - 4>(v, twl, t);
-    dif_rounds_after1<B, LQ>(v, tile, twl, t, q);
-}
-
-// registers in final layout (position pt_of<0>) -> LDS row = frequency rev_B(position) -> registers in the first
-// layout (row pt_of<B-4>): natural frequency order, 16 consecutive rows per 16 lanes.
+// registers in final layout (position pt_of<0>) -> LDS row = frequency rev_B(position) = (rev4(j) << (B-4)) | rev(t)
+// -> registers in the first layout (row pt_of<B-4>): natural frequency order, 16 consecutive rows per 16 lanes.
 template <int B, int LQ>
 __device__ __forceinline__ void to_natural(uint2* tile, uint2 (&v)[16], uint32_t t, uint32_t q) {
     __syncthreads();
     const uint32_t rt = rev_bits(t, B - 4);
+    uint2* wp = tile + (((rt + (rt >> 4)) << LQ) + q);
 #pragma unroll
-    for (uint32_t j = 0; j < 16; j++) tile[(sig<LQ>((crev(j, 4) << (B - 4)) | rt) << LQ) + q] = v[j];
+    for (uint32_t j = 0; j < 16; j++) wp[lds_joff<LQ>(crev(j, 4) << (B - 4))] = v[j];
     __syncthreads();
+    const uint2* rp = tile + lds_base<LQ, B - 4>(t, q);
 #pragma unroll
-    for (uint32_t j = 0; j < 16; j++) v[j] = tile[(sig<LQ>(pt_of<B - 4>(t, j)) << LQ) + q];
+    for (uint32_t j = 0; j < 16; j++) v[j] = rp[lds_joff<LQ>(j << (B - 4))];
 }
 // same hand-over without the bit reversal (K3: position order is already the wanted order)
 template <int B, int LQ>
 __device__ __forceinline__ void to_rows(uint2* tile, uint2 (&v)[16], uint32_t t, uint32_t q) {
-    __syncthreads();
-#pragma unroll
-    for (uint32_t j = 0; j < 16; j++) tile[(sig<LQ>(pt_of<0>(t, j)) << LQ) + q] = v[j];
-    __syncthreads();
-#pragma unroll
-    for (uint32_t j = 0; j < 16; j++) v[j] = tile[(sig<LQ>(pt_of<B - 4>(t, j)) << LQ) + q];
+    exchange<LQ, 0, B - 4>(tile, v, t, q);
 }
 
 // Adjacent tiles (four of them for 32-byte segments) share 128-byte lines of the strided side: keep them on one XCD (workgroups are dealt to
@@ -180,6 +188,15 @@ __device__ __forceinline__ uint32_t tile_of_block(uint32_t bid, uint32_t remap) 
     constexpr uint32_t LG = 4 - LQ;  // log2(tiles per 128-byte line)
     const uint32_t xcd = bid & 7u, s = bid >> 3;
     return ((s >> LG) << (LG + 3)) | (xcd << LG) | (s & ((1u << LG) - 1u));
+}
+
+// Global accesses as UNIFORM base + 32-bit per-lane byte offset (global_load/store ... saddr): the sixteen row
+// offsets of a lane's points are uniform, so they live in SGPRs instead of sixteen 64-bit VGPR addresses.
+__device__ __forceinline__ uint2 ld2(const void* base, uint32_t off) {
+    return *reinterpret_cast<const uint2*>(static_cast<const char*>(base) + off);
+}
+__device__ __forceinline__ void st2(void* base, uint32_t off, uint2 v) {
+    *reinterpret_cast<uint2*>(static_cast<char*>(base) + off) = v;
 }
 
 // v[j] *= c * phi^(idx(j)), idx(j) = REV ? rev4(j) : j
@@ -200,15 +217,15 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow_inv1_kernel(NarrowAr
     constexpr uint32_t NQ = 1u << LQ, NTH = 1u << (B - 4 + LQ);
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint2* tile = reinterpret_cast<uint2*>(smem);
-    uint32_t* twl = smem + (2u << (B + LQ));                                // stages below B-4: 2^(B-4) - 1 words
+    uint32_t* twl = smem + (2u * lds_rows(B) << LQ);                                // stages below B-4: 2^(B-4) - 1 words
     const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> LQ;
     const uint32_t s = tile_of_block<LQ>(blockIdx.x, a.xcd_remap) * NQ + q;  // 8-byte slot within a row group of N2 rows
     const uint32_t lo = s >> a.wsl, cp = s & ((1u << a.wsl) - 1u);
-    const uint64_t rowstride = ((uint64_t)a.W << a.n2);                   // words between r1 and r1 + 1
-    const uint32_t* p = a.src + 2ull * s;
+    const uint32_t rowstride = a.W << a.n2;                               // words between r1 and r1 + 1
+    const uint32_t ld_off = (2u * s + t * rowstride) * 4u;
     uint2 v[16];
 #pragma unroll
-    for (uint32_t j = 0; j < 16; j++) v[j] = *reinterpret_cast<const uint2*>(p + (uint64_t)pt_of<B - 4>(t, j) * rowstride);
+    for (uint32_t j = 0; j < 16; j++) v[j] = ld2(a.src + ((uint64_t)j << (B - 4)) * rowstride, ld_off);
     uint32_t w1[15];
     load_round1_twiddles<B>(a.stage_tw, t, w1);
     for (uint32_t i = threadIdx.x; i + 1 < (1u << (B - 4)); i += NTH) twl[i] = a.stage_tw[i];
@@ -219,34 +236,34 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow_inv1_kernel(NarrowAr
     scale_ladder<true>(v, c, phi);
     to_natural<B, LQ>(tile, v, t, q);
     // T[(lo * N1 + k1) * W + 2 cp], k1 = pt_of<B-4>(t, j): 16 lanes x 8 bytes contiguous per (lo, cp)
-    uint32_t* o = a.dst + (((uint64_t)lo << B) * a.W + 2u * cp);
+    const uint32_t st_off = (((lo << B) + t) * a.W + 2u * cp) * 4u;
 #pragma unroll
-    for (uint32_t j = 0; j < 16; j++) *reinterpret_cast<uint2*>(o + (uint64_t)pt_of<B - 4>(t, j) * a.W) = v[j];
+    for (uint32_t j = 0; j < 16; j++) st2(a.dst + ((uint64_t)j << (B - 4)) * a.W, st_off, v[j]);
 }
 
 // K2: second inverse digit, then per coset: scale, first forward digit, twiddle, strided store.
 template <int B, int LQ>
-__global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow_mid_kernel(NarrowArgs a) {
+__global__ void __launch_bounds__(1 << (B - 4 + LQ), (B - 4 + LQ >= 9 && NARROW_MID_SHARE_CU) ? 4 : 1) narrow_mid_kernel(NarrowArgs a) {
     using namespace narrow;
     constexpr uint32_t NQ = 1u << LQ, NTH = 1u << (B - 4 + LQ);
-    constexpr bool LEAN = NTH >= 1024;  // 128 VGPRs per lane: rebuild the output ladder per coset
+    constexpr bool LEAN = NTH >= 512;  // 128 VGPRs per lane: rebuild the output ladder per coset
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint2* tile = reinterpret_cast<uint2*>(smem);
-    uint32_t* twl_i = smem + (2u << (B + LQ));   // inverse stages below B-4
-    uint32_t* twl_f = twl_i + (1u << (B - 4)); // forward table, all B stages
+    uint32_t* twl_i = smem + (2u * lds_rows(B) << LQ);   // inverse stages below B-4
+    uint32_t* twl_f = twl_i + (1u << (B - 4)); // forward stages below B-4
     const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> LQ;
     const uint32_t s = tile_of_block<LQ>(blockIdx.x, a.xcd_remap) * NQ + q;  // slot within a group of N1 rows
     const uint32_t k1 = s >> a.wsl;
-    const uint64_t rowstride = ((uint64_t)a.W << a.n1);
-    const uint32_t* p = a.src + 2ull * s;
+    const uint32_t rowstride = a.W << a.n1;
+    const uint32_t ld_off = (2u * s + t * rowstride) * 4u, st_off = (2u * s + (t << 4) * rowstride) * 4u;
     uint2 c[16];
 #pragma unroll
-    for (uint32_t j = 0; j < 16; j++) c[j] = *reinterpret_cast<const uint2*>(p + (uint64_t)pt_of<B - 4>(t, j) * rowstride);
+    for (uint32_t j = 0; j < 16; j++) c[j] = ld2(a.src + ((uint64_t)j << (B - 4)) * rowstride, ld_off);
     {
         uint32_t w1[15];
         load_round1_twiddles<B>(a.stage_tw, t, w1);
         for (uint32_t i = threadIdx.x; i + 1 < (1u << (B - 4)); i += NTH) twl_i[i] = a.stage_tw[i];
-        for (uint32_t i = threadIdx.x; i + 1 < (1u << B); i += NTH) twl_f[i] = a.stage_tw_fwd[i];
+        for (uint32_t i = threadIdx.x; i + 1 < (1u << (B - 4)); i += NTH) twl_f[i] = a.stage_tw_fwd[i];
         dif_rounds<B, LQ>(c, tile, w1, twl_i, t, q);
     }
     // forward twiddle w^(k1 * m1), m1 = rev_B(position): the same for every coset
@@ -255,26 +272,27 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow_mid_kernel(NarrowArg
     const uint64_t kbase = (uint64_t)k1 + ((uint64_t)t << a.n1);
     uint32_t sc_next = two_level(a.sc_lo[0], a.sc_hi[0], a.sc_T, kbase);
     to_natural<B, LQ>(tile, c, t, q);  // c[j] = coefficient k = k1 + N1 * k2, k2 = pt_of<B-4>(t, j) = (j << (B-4)) | t
-    uint32_t pw2[LEAN ? 1 : 16];
+    uint32_t pw2[16];
     if constexpr (!LEAN) power_ladder<16>(c0, phi0, pw2);
     const uint32_t ncos = 1u << a.added;
     for (uint32_t jc = 0; jc < ncos; jc++) {
         const uint32_t sc = sc_next;
         if (jc + 1 < ncos) sc_next = two_level(a.sc_lo[jc + 1], a.sc_hi[jc + 1], a.sc_T, kbase);
+        uint32_t w1[15];  // in flight while the scale ladder runs
+        load_round1_twiddles<B>(a.stage_tw_fwd, t, w1);
         uint2 v[16];
 #pragma unroll
         for (uint32_t j = 0; j < 16; j++) v[j] = c[j];
         scale_ladder<false>(v, sc, a.sc_phi[jc]);
-        dif_rounds_lds<B, LQ>(v, tile, twl_f, t, q);
-        uint32_t* o = a.dst + (((uint64_t)rev_bits(jc, a.added) << a.n) * a.W + 2ull * s);
+        dif_rounds<B, LQ>(v, tile, w1, twl_f, t, q);
+        uint32_t* o = a.dst + ((uint64_t)rev_bits(jc, a.added) << a.n) * a.W;  // position (t << 4) | j of the coset's block
         if constexpr (LEAN) {
             scale_ladder<true>(v, c0, phi0);
 #pragma unroll
-            for (uint32_t j = 0; j < 16; j++) *reinterpret_cast<uint2*>(o + (uint64_t)pt_of<0>(t, j) * rowstride) = v[j];
+            for (uint32_t j = 0; j < 16; j++) st2(o + (uint64_t)j * rowstride, st_off, v[j]);
         } else {
 #pragma unroll
-            for (uint32_t j = 0; j < 16; j++)
-                *reinterpret_cast<uint2*>(o + (uint64_t)pt_of<0>(t, j) * rowstride) = mul2(v[j], pw2[crev(j, 4)]);
+            for (uint32_t j = 0; j < 16; j++) st2(o + (uint64_t)j * rowstride, st_off, mul2(v[j], pw2[crev(j, 4)]));
         }
     }
 }
@@ -286,21 +304,22 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow_fwd2_kernel(NarrowAr
     constexpr uint32_t NQ = 1u << LQ, NTH = 1u << (B - 4 + LQ);
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint2* tile = reinterpret_cast<uint2*>(smem);
-    uint32_t* twl = smem + (2u << (B + LQ));
+    uint32_t* twl = smem + (2u * lds_rows(B) << LQ);
     const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> LQ;
     const uint32_t s = blockIdx.x * NQ + q;
-    const uint32_t blk = s >> a.wsl, cp = s & ((1u << a.wsl) - 1u);
-    uint32_t* p = a.dst + (((uint64_t)blk << B) * a.W + 2u * cp);
+    const uint32_t blk0 = (blockIdx.x * NQ) >> a.wsl, blk = s >> a.wsl, cp = s & ((1u << a.wsl) - 1u);
+    uint32_t* p = a.dst + ((uint64_t)blk0 << B) * a.W;                    // uniform: the workgroup's first block
+    const uint32_t off = ((((blk - blk0) << B) + t) * a.W + 2u * cp) * 4u;
     uint2 v[16];
 #pragma unroll
-    for (uint32_t j = 0; j < 16; j++) v[j] = *reinterpret_cast<const uint2*>(p + (uint64_t)pt_of<B - 4>(t, j) * a.W);
+    for (uint32_t j = 0; j < 16; j++) v[j] = ld2(p + ((uint64_t)j << (B - 4)) * a.W, off);
     uint32_t w1[15];
     load_round1_twiddles<B>(a.stage_tw, t, w1);
     for (uint32_t i = threadIdx.x; i + 1 < (1u << (B - 4)); i += NTH) twl[i] = a.stage_tw[i];
     dif_rounds<B, LQ>(v, tile, w1, twl, t, q);
     to_rows<B, LQ>(tile, v, t, q);
 #pragma unroll
-    for (uint32_t j = 0; j < 16; j++) *reinterpret_cast<uint2*>(p + (uint64_t)pt_of<B - 4>(t, j) * a.W) = v[j];
+    for (uint32_t j = 0; j < 16; j++) st2(p + ((uint64_t)j << (B - 4)) * a.W, off, v[j]);
 }
 
 }  // namespace p3

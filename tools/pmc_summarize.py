@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Turns the two rocprofv3 PMC passes of tools/pmc_probe.py (FETCH_SIZE and WRITE_SIZE, collected in SEPARATE runs)
+into the per-launch HBM-side traffic table that bench.py reports as roofline.traffic:
+   python tools/pmc_summarize.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_lde_v2.json
+Counter units are KiB; FETCH_SIZE is doubled (gfx950 reports half of the streamed read bytes,
+MI355X_MICROARCH.md HBM section; the calibration kernels with known byte counts confirm it)."""
+import csv
+import glob
+import json
+import sys
+
+
+def read(dirname, counter):
+    path = glob.glob(dirname + "/**/*counter_collection.csv", recursive=True)[0]
+    rows = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] == counter:
+                rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"], float(r["Counter_Value"])))
+    rows.sort()
+    return rows
+
+
+fetch, write = read(sys.argv[1], "FETCH_SIZE"), read(sys.argv[2], "WRITE_SIZE")
+assert [k for _, k, _ in fetch] == [k for _, k, _ in write], "the two passes must run the same launches"
+launches = [{"kernel": k[:60], "fetch_bytes": 2.0 * f * 1024, "write_bytes": w * 1024}
+            for (_, k, f), (_, _, w) in zip(fetch, write)]
+
+
+def unit(names, which):
+    """the `which`-th (from the end) consecutive run of launches whose kernel names start with `names` in order"""
+    idx = [i for i in range(len(launches) - len(names) + 1)
+           if all(launches[i + j]["kernel"].startswith(n) for j, n in enumerate(names))]
+    i = idx[which]
+    return launches[i:i + len(names)]
+
+
+def first(prefix):
+    return next(l for l in launches if prefix in l["kernel"])
+
+
+out = {
+    "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE runs of tools/pmc_probe.py; "
+              "counters are KiB; FETCH_SIZE doubled (gfx950 reports 1/2 of streamed read bytes, MI355X_MICROARCH.md HBM "
+              "section); summarised by tools/pmc_summarize.py",
+    "calibration_bytes": {
+        "fib_trace 2^24 rows (writes 128 MiB)": first("fib_trace_kernel"),
+        "poseidon2 permute 2^22 states in place (reads 256 MiB, writes 256 MiB)": first("poseidon2_permute"),
+        "leaf hash 2^24 x 2 (reads 128 MiB, writes 512 MiB)": first("leaf_hash"),
+    },
+}
+k3 = ["void p3::narrow_inv1_kernel", "void p3::narrow_mid_kernel", "void p3::narrow_fwd2_kernel"]
+for key, names, which, alg in (("cfg3_lde_2^24x2_blowup4", [n + "<12" for n in k3], -1, 4 * (1 << 24) * 2 * 5),
+                               ("cfg2_lde_2^20x2_blowup2", [n + "<10" for n in k3], -1, 4 * (1 << 20) * 2 * 3)):
+    u = unit(names, which)
+    out[key] = {"launches": u, "total_bytes": sum(l["fetch_bytes"] + l["write_bytes"] for l in u), "algorithmic_bytes": alg}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps({k: (v["total_bytes"], v["algorithmic_bytes"]) for k, v in out.items() if k.startswith("cfg")}))

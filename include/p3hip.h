@@ -120,6 +120,17 @@ void p3hip_mmcs_free(p3hip_tree_t *tree);
 int p3hip_mmcs_commit(const uint32_t *const *mats, const size_t *heights, const size_t *widths,
                       size_t n_mats, uint32_t root_out[8], p3hip_tree_t **tree_out);
 
+/* ---- the reference's own hash configuration (native/src/fib_air.rs:28-38): U64Hash = PaddingFreeSponge<KeccakF, 25,
+ *      17, 4>, FieldHash = SerializingHasher<U64Hash>, MyCompress = CompressionFunctionFromHasher<U64Hash, 2, 4>.
+ *      Digests are [u64; 4], stored as 8 little-endian u32 words, so trees of both configurations share
+ *      p3hip_mmcs_root / open_batch / layer_dev / free.  Non-hiding (MerkleTreeMmcs, not MerkleTreeHidingMmcs). ---- */
+#define P3HIP_HASH_POSEIDON2 0
+#define P3HIP_HASH_KECCAK 1
+int p3hip_mmcs_commit_hash_dev(int hash, const uint32_t *const *d_mats, const size_t *heights, const size_t *widths,
+                               size_t n_mats, uint32_t root_out[8], p3hip_tree_t **tree_out, void *stream);
+/* KeccakF::permute_mut on n independent [u64; 25] states in device memory (p3-keccak's KeccakF, fib_air.rs:32) */
+int p3hip_keccak_f_dev(uint64_t *d_states, size_t n, void *stream);
+
 /* ---- fib_air prover: p3_uni_stark::prove(&config, &FibonacciAir{}, trace, &pis) as called at
  *      native/src/fib_air.rs:70, for StarkConfig<TwoAdicFriPcs<BabyBear, Dft, Poseidon2 Mmcs, ExtensionMmcs>,
  *      BinomialExtensionField<BabyBear,4>, DuplexChallenger<BabyBear, Poseidon2-16, 16, 8>> ---------------- */

@@ -34,7 +34,14 @@ void p3o_compress(const uint32_t l[8], const uint32_t r[8], uint32_t out[8]) {
     memcpy(out, st, 32);
 }
 
+/* hash configuration of a tree: 0 = Poseidon2 (north_star), 1 = Keccak (keccak.c, the reference's own) */
+typedef void (*hash_row_fn)(const uint32_t *, size_t, uint32_t[8]);
+typedef void (*compress_fn)(const uint32_t[8], const uint32_t[8], uint32_t[8]);
+static hash_row_fn hash_of(int kind) { return kind ? p3o_keccak_hash_row : p3o_hash_row; }
+static compress_fn compress_of(int kind) { return kind ? p3o_keccak_compress : p3o_compress; }
+
 struct p3o_tree {
+    int kind;
     size_t n_mats;
     const uint32_t **mats; size_t *heights, *widths; /* borrowed matrix pointers */
     size_t n_layers; size_t *layer_len; uint32_t **layers;
@@ -54,7 +61,7 @@ static void hash_rows_of_height(const p3o_tree_t *t, size_t h, size_t row, uint3
         memcpy(buf + off, t->mats[m] + row * t->widths[m], t->widths[m] * 4);
         off += t->widths[m];
     }
-    p3o_hash_row(buf, tot, out);
+    hash_of(t->kind)(buf, tot, out);
     free(buf);
 }
 static int has_height(const p3o_tree_t *t, size_t h) {
@@ -65,12 +72,14 @@ static int has_height(const p3o_tree_t *t, size_t h) {
 /* MerkleTree::new: first_digest_layer over the tallest matrices, then per layer
  * compress pairs and, where matrices of that height exist, compress in their row hash
  * (compress_and_inject).  Only power-of-two heights are accepted here. */
-p3o_tree_t *p3o_mmcs_commit(const uint32_t *const *mats, const size_t *heights,
-                            const size_t *widths, size_t n, uint32_t root_out[8]) {
+p3o_tree_t *p3o_mmcs_commit_kind(int kind, const uint32_t *const *mats, const size_t *heights,
+                                 const size_t *widths, size_t n, uint32_t root_out[8]) {
     if (!n) return NULL;
+    compress_fn compress = compress_of(kind);
     size_t maxh = 0;
     for (size_t i = 0; i < n; i++) { if (!is_pow2(heights[i])) return NULL; if (heights[i] > maxh) maxh = heights[i]; }
     p3o_tree_t *t = calloc(1, sizeof *t);
+    t->kind = kind;
     t->n_mats = n;
     t->mats = malloc(n * sizeof *t->mats); t->heights = malloc(n * sizeof(size_t)); t->widths = malloc(n * sizeof(size_t));
     for (size_t i = 0; i < n; i++) { t->mats[i] = mats[i]; t->heights[i] = heights[i]; t->widths[i] = widths[i]; }
@@ -91,16 +100,20 @@ p3o_tree_t *p3o_mmcs_commit(const uint32_t *const *mats, const size_t *heights,
         #pragma omp parallel for schedule(static) if (len >= 256)
         for (size_t i = 0; i < len; i++) {
             uint32_t d[8];
-            p3o_compress(t->layers[l - 1] + 2 * i * 8, t->layers[l - 1] + (2 * i + 1) * 8, d);
+            compress(t->layers[l - 1] + 2 * i * 8, t->layers[l - 1] + (2 * i + 1) * 8, d);
             if (inject) {
                 uint32_t rh[8];
                 hash_rows_of_height(t, len, i, rh);
-                p3o_compress(d, rh, t->layers[l] + i * 8);
+                compress(d, rh, t->layers[l] + i * 8);
             } else memcpy(t->layers[l] + i * 8, d, 32);
         }
     }
     memcpy(root_out, t->layers[t->n_layers - 1], 32);
     return t;
+}
+p3o_tree_t *p3o_mmcs_commit(const uint32_t *const *mats, const size_t *heights,
+                            const size_t *widths, size_t n, uint32_t root_out[8]) {
+    return p3o_mmcs_commit_kind(0, mats, heights, widths, n, root_out);
 }
 size_t p3o_tree_num_layers(const p3o_tree_t *t) { return t->n_layers; }
 size_t p3o_tree_layer_len(const p3o_tree_t *t, size_t l) { return t->layer_len[l]; }
@@ -123,9 +136,11 @@ int p3o_mmcs_open_batch(const p3o_tree_t *t, size_t index, uint32_t *rows_out, u
 }
 
 /* MerkleTreeMmcs::verify_batch for power-of-two heights; rows = opened rows in matrix order. */
-int p3o_mmcs_verify_batch(const uint32_t root[8], const size_t *heights, const size_t *widths,
-                          size_t n, size_t index, const uint32_t *rows, const uint32_t *path,
-                          size_t path_len) {
+int p3o_mmcs_verify_batch_kind(int kind, const uint32_t root[8], const size_t *heights, const size_t *widths,
+                               size_t n, size_t index, const uint32_t *rows, const uint32_t *path,
+                               size_t path_len) {
+    hash_row_fn hash_row = hash_of(kind);
+    compress_fn compress = compress_of(kind);
     size_t maxh = 0;
     for (size_t i = 0; i < n; i++) if (heights[i] > maxh) maxh = heights[i];
     if (!n || path_len != log2_exact(maxh)) return -1;
@@ -137,17 +152,22 @@ int p3o_mmcs_verify_batch(const uint32_t root[8], const size_t *heights, const s
     for (size_t level = 0;; level++) {
         size_t k = 0; int any = 0;
         for (size_t m = 0; m < n; m++) if (heights[m] == h) { memcpy(buf + k, rows + offs[m], widths[m] * 4); k += widths[m]; any = 1; }
-        if (level == 0) p3o_hash_row(buf, k, cur);
-        else if (any) { uint32_t rh[8], d[8]; p3o_hash_row(buf, k, rh); p3o_compress(cur, rh, d); memcpy(cur, d, 32); }
+        if (level == 0) hash_row(buf, k, cur);
+        else if (any) { uint32_t rh[8], d[8]; hash_row(buf, k, rh); compress(cur, rh, d); memcpy(cur, d, 32); }
         if (h == 1) break;
         uint32_t d[8];
         const uint32_t *sib = path + level * 8;
-        if ((index >> level) & 1) p3o_compress(sib, cur, d); else p3o_compress(cur, sib, d);
+        if ((index >> level) & 1) compress(sib, cur, d); else compress(cur, sib, d);
         memcpy(cur, d, 32);
         h >>= 1;
     }
     free(buf); free(offs);
     return memcmp(cur, root, 32) == 0 ? 0 : 1;
+}
+int p3o_mmcs_verify_batch(const uint32_t root[8], const size_t *heights, const size_t *widths,
+                          size_t n, size_t index, const uint32_t *rows, const uint32_t *path,
+                          size_t path_len) {
+    return p3o_mmcs_verify_batch_kind(0, root, heights, widths, n, index, rows, path, path_len);
 }
 void p3o_mmcs_free(p3o_tree_t *t) {
     if (!t) return;

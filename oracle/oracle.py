@@ -49,6 +49,7 @@ def lib():
         L.p3o_two_adic_generator.restype = C.c_uint32
         L.p3o_two_adic_generator.argtypes = [C.c_uint]
         L.p3o_mmcs_commit.restype = C.c_void_p
+        L.p3o_mmcs_commit_kind.restype = C.c_void_p
         L.p3o_tree_layer.restype = _u32p
         L.p3o_tree_layer.argtypes = [C.c_void_p, C.c_size_t]
         for name in ("p3o_tree_num_layers", "p3o_tree_log_max_height"):
@@ -156,14 +157,15 @@ def compress(left, right):
 class Tree:
     """MerkleTreeMmcs prover data: keeps the matrices alive, exposes digest layers."""
 
-    def __init__(self, mats):
+    def __init__(self, mats, kind=0):
+        self.kind = kind
         self.mats = [_u32(m) for m in mats]
         n = len(self.mats)
         ptrs = (_u32p * n)(*[_p(m) for m in self.mats])
         hs = (C.c_size_t * n)(*[m.shape[0] for m in self.mats])
         ws = (C.c_size_t * n)(*[m.shape[1] for m in self.mats])
         self.root = np.zeros(8, dtype=np.uint32)
-        self._h = lib().p3o_mmcs_commit(ptrs, hs, ws, C.c_size_t(n), _p(self.root))
+        self._h = lib().p3o_mmcs_commit_kind(C.c_int(kind), ptrs, hs, ws, C.c_size_t(n), _p(self.root))
         if not self._h:
             raise ValueError("oracle mmcs: power-of-two heights required")
         self.log_max_height = lib().p3o_tree_log_max_height(self._h)
@@ -191,19 +193,43 @@ class Tree:
             self._h = None
 
 
-def mmcs_commit(mats):
-    t = Tree(mats)
+HASH_POSEIDON2, HASH_KECCAK = 0, 1
+
+
+def mmcs_commit(mats, kind=HASH_POSEIDON2):
+    """kind HASH_KECCAK = the reference's own hash configuration (native/src/fib_air.rs:28-38, keccak.c)."""
+    t = Tree(mats, kind)
     return t.root.copy(), t
 
 
-def mmcs_verify_batch(root, dims, index, rows, path):
+def keccak_f(state):
+    """Keccak-f[1600] on 25 u64 lanes (numpy uint64[25]) -> new array."""
+    a = np.ascontiguousarray(state, dtype=np.uint64).copy()
+    lib().p3o_keccak_f(a.ctypes.data_as(C.c_void_p))
+    return a
+
+
+def keccak_hash_row(items):
+    out = np.zeros(8, dtype=np.uint32)
+    items = _u32(items).reshape(-1)
+    lib().p3o_keccak_hash_row(_p(items), C.c_size_t(items.size), _p(out))
+    return out
+
+
+def keccak_compress(left, right):
+    out = np.zeros(8, dtype=np.uint32)
+    lib().p3o_keccak_compress(_p(_u32(left)), _p(_u32(right)), _p(out))
+    return out
+
+
+def mmcs_verify_batch(root, dims, index, rows, path, kind=HASH_POSEIDON2):
     n = len(dims)
     hs = (C.c_size_t * n)(*[d[0] for d in dims])
     ws = (C.c_size_t * n)(*[d[1] for d in dims])
     rows = _u32(rows).reshape(-1)
     path = _u32(path).reshape(-1, 8)
-    return lib().p3o_mmcs_verify_batch(_p(_u32(root)), hs, ws, C.c_size_t(n), C.c_size_t(index),
-                                       _p(rows), _p(path), C.c_size_t(path.shape[0])) == 0
+    return lib().p3o_mmcs_verify_batch_kind(C.c_int(kind), _p(_u32(root)), hs, ws, C.c_size_t(n), C.c_size_t(index),
+                                            _p(rows), _p(path), C.c_size_t(path.shape[0])) == 0
 
 
 def set_threads(n):

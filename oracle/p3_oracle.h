@@ -61,6 +61,18 @@ int p3o_mmcs_verify_batch(const uint32_t root[8], const size_t *heights, const s
                           size_t n_mats, size_t index, const uint32_t *rows,
                           const uint32_t *path, size_t path_len);
 void p3o_mmcs_free(p3o_tree_t *t);
+/* kind 0 = Poseidon2 (as above), 1 = the reference's Keccak configuration (keccak.c) */
+p3o_tree_t *p3o_mmcs_commit_kind(int kind, const uint32_t *const *mats, const size_t *heights,
+                                 const size_t *widths, size_t n_mats, uint32_t root_out[8]);
+int p3o_mmcs_verify_batch_kind(int kind, const uint32_t root[8], const size_t *heights, const size_t *widths,
+                               size_t n_mats, size_t index, const uint32_t *rows,
+                               const uint32_t *path, size_t path_len);
+
+/* ---- keccak.c: Keccak-f[1600], PaddingFreeSponge<KeccakF,25,17,4>, SerializingHasher, CompressionFunctionFromHasher ---- */
+void p3o_keccak_f(uint64_t state[25]);
+void p3o_keccak_sponge_u64(const uint64_t *items, size_t n, uint64_t out[4]);
+void p3o_keccak_hash_row(const uint32_t *items, size_t n, uint32_t out[8]);
+void p3o_keccak_compress(const uint32_t left[8], const uint32_t right[8], uint32_t out[8]);
 
 /* ---- stark.c: fib_air prover / verifier (uni-stark + two-adic FRI PCS + duplex challenger) ---- */
 int p3o_prove_fib_air(uint64_t a, uint64_t b, unsigned log_n, unsigned log_blowup, unsigned log_final_poly_len,

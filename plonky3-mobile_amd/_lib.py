@@ -39,6 +39,9 @@ _SIGS = {
     "p3hip_mmcs_commit_async_dev": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                               C.POINTER(C.c_size_t), C.c_size_t, C.POINTER(C.c_void_p),
                                               C.c_void_p]),
+    "p3hip_mmcs_commit_hash_dev": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
+                                             C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
+    "p3hip_keccak_f_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "p3hip_mmcs_root": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "p3hip_mmcs_log_max_height": (C.c_size_t, [C.c_void_p]),
     "p3hip_mmcs_num_layers": (C.c_size_t, [C.c_void_p]),

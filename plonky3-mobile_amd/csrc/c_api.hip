@@ -240,18 +240,40 @@ struct p3hip_tree {
     Tree* t;
 };
 
-int p3hip_mmcs_commit_async_dev(const uint32_t* const* d_mats, const size_t* heights, const size_t* widths,
-                                size_t n_mats, p3hip_tree_t** tree_out, void* stream) {
+static int commit_async_kind(int kind, const uint32_t* const* d_mats, const size_t* heights, const size_t* widths,
+                             size_t n_mats, p3hip_tree_t** tree_out, void* stream) {
     return guarded([&]() -> int {
         if (!tree_out) return fail(ERR_BAD_ARG, "mmcs_commit: null tree_out");
         Context* cx;
         int rc = get_context(&cx);
         if (rc) return rc;
         Tree* t = nullptr;
-        rc = mmcs_commit((hipStream_t)stream, d_mats, heights, widths, n_mats, &t);
+        rc = mmcs_commit((hipStream_t)stream, d_mats, heights, widths, n_mats, &t, nullptr, nullptr, kind);
         if (rc) return rc;
         *tree_out = new p3hip_tree{t};
         return OK;
+    });
+}
+int p3hip_mmcs_commit_async_dev(const uint32_t* const* d_mats, const size_t* heights, const size_t* widths,
+                                size_t n_mats, p3hip_tree_t** tree_out, void* stream) {
+    return commit_async_kind(HASH_POSEIDON2, d_mats, heights, widths, n_mats, tree_out, stream);
+}
+int p3hip_mmcs_commit_hash_dev(int hash, const uint32_t* const* d_mats, const size_t* heights, const size_t* widths,
+                               size_t n_mats, uint32_t root_out[8], p3hip_tree_t** tree_out, void* stream) {
+    if (!root_out) return fail(ERR_BAD_ARG, "mmcs_commit: null root_out");
+    int rc = commit_async_kind(hash, d_mats, heights, widths, n_mats, tree_out, stream);
+    if (rc) return rc;
+    rc = p3hip_mmcs_root(*tree_out, root_out, stream);
+    if (rc) { p3hip_mmcs_free(*tree_out); *tree_out = nullptr; }
+    return rc;
+}
+int p3hip_keccak_f_dev(uint64_t* d_states, size_t n, void* stream) {
+    return guarded([&]() -> int {
+        if (!d_states && n) return fail(ERR_BAD_ARG, "keccak_f: null states");
+        Context* cx;
+        int rc = get_context(&cx);
+        if (rc) return rc;
+        return keccak_f_states((hipStream_t)stream, d_states, n);
     });
 }
 int p3hip_mmcs_root(const p3hip_tree_t* tree, uint32_t root_out[8], void* stream) {

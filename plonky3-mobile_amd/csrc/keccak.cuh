@@ -1,0 +1,59 @@
+// Keccak-f[1600], one state per lane (25 x u64 = 50 VGPRs), for the hash configuration the reference itself wires
+// into its MMCS (native/src/fib_air.rs:28-38: PaddingFreeSponge<KeccakF, 25, 17, 4>, SerializingHasher,
+// CompressionFunctionFromHasher<_, 2, 4>; p3-keccak 0.4.2 -> tiny-keccak 2.0.2, both absent: FIPS 202 restated).
+// One round is fully unrolled (rho/pi are register renames, rotations are constant v_alignbit pairs, chi is
+// v_bfi/v_xor), the 24 rounds stay ROLLED so the kernel's code stays inside the instruction cache — the same
+// lesson as the Poseidon2 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kk {
+
+static __device__ __constant__ uint64_t d_rc[24] = {
+    0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+    0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+    0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+    0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+    0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+    0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+
+__device__ __forceinline__ constexpr unsigned rho(int i) {
+    constexpr unsigned R[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+    return R[i];
+}
+template <unsigned N>
+__device__ __forceinline__ uint64_t rotl(uint64_t v) {
+    if constexpr (N == 0) return v;
+    else return (v << N) | (v >> (64 - N));
+}
+
+__device__ __forceinline__ void round(uint64_t (&a)[25], uint64_t rc) {
+    uint64_t c[5], b[25];
+#pragma unroll
+    for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+#pragma unroll
+    for (int x = 0; x < 5; x++) {
+        const uint64_t d = c[(x + 4) % 5] ^ rotl<1>(c[(x + 1) % 5]);
+#pragma unroll
+        for (int y = 0; y < 5; y++) a[x + 5 * y] ^= d;
+    }
+    // rho + pi: B[y, 2x + 3y] = rot(A[x, y], r[x, y]); written out so that every rotation count is a constant
+#define KK_RP(x, y) b[(y) + 5 * ((2 * (x) + 3 * (y)) % 5)] = rotl<rho((x) + 5 * (y))>(a[(x) + 5 * (y)]);
+#define KK_ROW(y) KK_RP(0, y) KK_RP(1, y) KK_RP(2, y) KK_RP(3, y) KK_RP(4, y)
+    KK_ROW(0) KK_ROW(1) KK_ROW(2) KK_ROW(3) KK_ROW(4)
+#undef KK_ROW
+#undef KK_RP
+#pragma unroll
+    for (int y = 0; y < 5; y++)
+#pragma unroll
+        for (int x = 0; x < 5; x++) a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
+    a[0] ^= rc;
+}
+
+__device__ __forceinline__ void permute(uint64_t (&a)[25]) {
+    _Pragma("clang loop unroll(disable)")
+    for (int r = 0; r < 24; r++) round(a, d_rc[r]);
+}
+
+}  // namespace kk

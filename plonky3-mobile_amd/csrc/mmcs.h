@@ -6,7 +6,10 @@
 
 namespace p3 {
 
+enum HashKind : int { HASH_POSEIDON2 = 0, HASH_KECCAK = 1 };
+
 struct Tree {
+    int kind = HASH_POSEIDON2;
     std::vector<const uint32_t*> mats;  // borrowed device pointers (or entries of `owned`)
     std::vector<size_t> heights, widths;
     std::vector<void*> owned;           // device copies made by the host-pointer commit
@@ -22,10 +25,12 @@ struct Tree {
 
 // ext_layers: optional caller-owned storage of (2*max_height - 1) * 8 words for the digest layers.
 int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t* heights, const size_t* widths,
-                size_t n_mats, Tree** out, uint32_t* ext_layers = nullptr, uint32_t* root_copy = nullptr);
+                size_t n_mats, Tree** out, uint32_t* ext_layers = nullptr, uint32_t* root_copy = nullptr,
+                int kind = HASH_POSEIDON2);
 inline size_t mmcs_layer_words(uint64_t max_height) { return (size_t)(2 * max_height - 1) * 8; }
 int mmcs_root(hipStream_t stream, const Tree& t, uint32_t root_out[8]);
 int mmcs_open(hipStream_t stream, const Tree& t, uint64_t index, uint32_t* rows_out, uint32_t* path_out);
 int poseidon2_permute_states(hipStream_t stream, uint32_t* d_states, uint64_t n);
+int keccak_f_states(hipStream_t stream, uint64_t* d_states, uint64_t n);
 
 }  // namespace p3

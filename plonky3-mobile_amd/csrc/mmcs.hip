@@ -14,6 +14,7 @@
 #include "poseidon2.cuh"
 #include "poseidon2_coop.cuh"
 #include "poseidon2_f64.cuh"
+#include "keccak.cuh"
 
 namespace p3 {
 
@@ -294,6 +295,87 @@ int poseidon2_permute_states(hipStream_t stream, uint32_t* d_states, uint64_t n)
     return OK;
 }
 
+// ---- the reference's own hash configuration (native/src/fib_air.rs:28-38): Keccak-f[1600] sponge over u64 lanes ----
+// SerializingHasher: the concatenated row's field elements (Montgomery words) are packed two per u64, first in the
+// low half; PaddingFreeSponge<KeccakF, 25, 17, 4>: overwrite 17 lanes per block, permute after every full block and
+// after a non-empty partial one; digest = lanes 0..3 = 8 words.
+__device__ __forceinline__ uint32_t rowset_elem(const RowSet& rs, uint64_t r, uint32_t k, uint32_t& m, uint32_t& base) {
+    // element k of the concatenated row (k only ever increases between calls: m/base are the running cursor)
+    while (k - base >= rs.width[m]) { base += rs.width[m]; m++; }
+    return rs.ptr[m][r * rs.width[m] + (k - base)];
+}
+__device__ __forceinline__ void keccak_sponge_row(const RowSet& rs, uint64_t r, uint64_t (&st)[25]) {
+#pragma unroll
+    for (int i = 0; i < 25; i++) st[i] = 0;
+    const uint32_t n = rs.total, n64 = (n + 1) / 2;
+    uint32_t m = 0, base = 0;
+    for (uint32_t i = 0; i < n64; i += 17) {
+#pragma unroll
+        for (int k = 0; k < 17; k++) {
+            const uint32_t e = 2 * (i + k);
+            if (e < n) {
+                uint64_t lo = rowset_elem(rs, r, e, m, base);
+                uint64_t hi = e + 1 < n ? rowset_elem(rs, r, e + 1, m, base) : 0u;
+                st[k] = lo | (hi << 32);
+            }
+        }
+        kk::permute(st);
+    }
+}
+__device__ __forceinline__ void store_digest64(uint32_t* p, const uint64_t (&st)[25]) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4((uint32_t)st[0], (uint32_t)(st[0] >> 32), (uint32_t)st[1], (uint32_t)(st[1] >> 32));
+    q[1] = make_uint4((uint32_t)st[2], (uint32_t)(st[2] >> 32), (uint32_t)st[3], (uint32_t)(st[3] >> 32));
+}
+__global__ void __launch_bounds__(256) keccak_leaf_kernel(RowSet rs, uint64_t n_rows, uint32_t* digests) {
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    uint64_t st[25];
+    keccak_sponge_row(rs, r, st);
+    store_digest64(digests + r * 8, st);
+}
+// CompressionFunctionFromHasher<U64Hash, 2, 4>: hash of the 8 lanes of the two child digests (one block)
+__global__ void __launch_bounds__(256) keccak_compress_kernel(const uint32_t* prev, uint32_t* next, uint64_t n_out,
+                                                              RowSet rs, uint32_t inject) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    uint32_t w[16];
+    load_digest(prev + i * 16, w);
+    load_digest(prev + i * 16 + 8, w + 8);
+    uint64_t st[25];
+#pragma unroll
+    for (int k = 0; k < 8; k++) st[k] = (uint64_t)w[2 * k] | ((uint64_t)w[2 * k + 1] << 32);
+#pragma unroll
+    for (int k = 8; k < 25; k++) st[k] = 0;
+    kk::permute(st);
+    if (inject) {
+        uint64_t h[25];
+        keccak_sponge_row(rs, i, h);
+#pragma unroll
+        for (int k = 0; k < 4; k++) st[4 + k] = h[k];
+#pragma unroll
+        for (int k = 8; k < 25; k++) st[k] = 0;
+        kk::permute(st);
+    }
+    store_digest64(next + i * 8, st);
+}
+__global__ void keccak_f_kernel(uint64_t* states, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t st[25];
+#pragma unroll
+    for (int k = 0; k < 25; k++) st[k] = states[i * 25 + k];
+    kk::permute(st);
+#pragma unroll
+    for (int k = 0; k < 25; k++) states[i * 25 + k] = st[k];
+}
+int keccak_f_states(hipStream_t stream, uint64_t* d_states, uint64_t n) {
+    if (!n) return OK;
+    hipLaunchKernelGGL(keccak_f_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_states, n);
+    P3_HIP(hipGetLastError());
+    return OK;
+}
+
 // Gathers one opening (rows of every matrix + sibling path) into a packed staging buffer.
 struct OpenArgs {
     const uint32_t* mat[64];
@@ -350,7 +432,8 @@ Tree::~Tree() {
 }
 
 int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t* heights, const size_t* widths,
-                size_t n_mats, Tree** out, uint32_t* ext_layers, uint32_t* root_copy) {
+                size_t n_mats, Tree** out, uint32_t* ext_layers, uint32_t* root_copy, int kind) {
+    if (kind != HASH_POSEIDON2 && kind != HASH_KECCAK) return fail(ERR_BAD_ARG, "mmcs_commit: unknown hash configuration");
     if (!n_mats || !d_mats || !heights || !widths || !out) return fail(ERR_BAD_ARG, "mmcs_commit: null/empty argument");
     if (n_mats > 64) return fail(ERR_BAD_ARG, "mmcs_commit: at most 64 matrices per commitment");
     uint64_t maxh = 0;
@@ -360,6 +443,7 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
         if (heights[i] > maxh) maxh = heights[i];
     }
     std::unique_ptr<Tree> t(new Tree());
+    t->kind = kind;
     for (size_t i = 0; i < n_mats; i++) { t->mats.push_back(d_mats[i]); t->heights.push_back(heights[i]); t->widths.push_back(widths[i]); }
     t->log_max_height = log2u(maxh);
     for (uint64_t h = maxh; h >= 1; h >>= 1) {
@@ -385,6 +469,21 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
     // Layers with fewer than COOP_MAX permutations cannot fill the chip with one state per lane: they run the
     // 16-lanes-per-state kernels (latency ~6x lower); the last <= 1024 digests finish inside one workgroup.
     const uint64_t COOP_MAX = 1u << 15;
+    if (kind == HASH_KECCAK) {
+        // one state per lane for every layer (no lane-cooperative form: the 64-bit lanes do not split over DPP rows)
+        RowSet rs0 = make_rowset(*t, maxh);
+        hipLaunchKernelGGL(keccak_leaf_kernel, dim3((uint32_t)((maxh + 255) / 256)), dim3(256), 0, stream, rs0, maxh, t->layers);
+        P3_HIP(hipGetLastError());
+        for (size_t l = 1; l < t->layer_len.size(); l++) {
+            uint64_t len = t->layer_len[l];
+            RowSet rs = make_rowset(*t, len);
+            hipLaunchKernelGGL(keccak_compress_kernel, dim3((uint32_t)((len + 255) / 256)), dim3(256), 0, stream,
+                               t->layers + t->layer_off[l - 1], t->layers + t->layer_off[l], len, rs, rs.count > 0 ? 1u : 0u);
+            P3_HIP(hipGetLastError());
+        }
+        *out = t.release();
+        return OK;
+    }
     {
         RowSet rs = make_rowset(*t, maxh);
         if (rs.count == 1 && maxh < COOP_MAX && maxh * 16 <= 0x7fffffffull) {

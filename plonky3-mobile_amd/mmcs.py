@@ -1,7 +1,8 @@
-"""Host-side mirror of Plonky3's Mmcs contract for the Poseidon2 Merkle tree
-(MerkleTreeMmcs<Poseidon2 sponge, TruncatedPermutation, digest 8>; the reference hands the Keccak
-flavour to the PCS at native/src/fib_air.rs:40-51).  commit / open_batch / get_matrices keep
-everything device-resident; verify_batch is the verifier's job and lives in the test oracle."""
+"""Host-side mirror of Plonky3's Mmcs contract: MerkleTreeMmcs over either hash configuration —
+"poseidon2" (north_star: Poseidon2 sponge 16/8/8 + TruncatedPermutation, digest 8 field elements) or "keccak"
+(what the reference itself wires at native/src/fib_air.rs:28-51: PaddingFreeSponge<KeccakF,25,17,4> behind
+SerializingHasher + CompressionFunctionFromHasher, digest [u64;4]; non-hiding).  commit / open_batch /
+get_matrices keep everything device-resident; verify_batch is the verifier's job and lives in the test oracle."""
 import ctypes as C
 
 import numpy as np
@@ -21,6 +22,24 @@ def poseidon2_permute(states):
     assert a.shape[-1] == 16
     _lib.check(L.p3hip_poseidon2_permute(a.ctypes.data_as(C.c_void_p), a.size // 16))
     return a
+
+
+HASH_POSEIDON2, HASH_KECCAK = 0, 1
+
+
+def keccak_f(states):
+    """KeccakF::permute_mut on n x 25 u64 states (torch CUDA int64 tensor in place, or numpy uint64 -> new array)."""
+    import torch
+    L = _lib.lib()
+    if _is_torch(states):
+        assert states.is_cuda and states.is_contiguous() and states.shape[-1] == 25 and states.element_size() == 8
+        _lib.check(L.p3hip_keccak_f_dev(C.c_void_p(states.data_ptr()), states.numel() // 25, _stream_ptr()))
+        return states
+    a = np.ascontiguousarray(states, dtype=np.uint64)
+    assert a.shape[-1] == 25
+    d = torch.from_numpy(a.view(np.int64).copy()).cuda()
+    _lib.check(L.p3hip_keccak_f_dev(C.c_void_p(d.data_ptr()), a.size // 25, _stream_ptr()))
+    return d.cpu().numpy().view(np.uint64).reshape(a.shape)
 
 
 class MerkleTree:
@@ -57,6 +76,12 @@ class MerkleTree:
 
 
 class MerkleTreeMmcs:
+    def __init__(self, hash="poseidon2"):
+        kinds = {"poseidon2": HASH_POSEIDON2, "keccak": HASH_KECCAK}
+        if hash not in kinds:
+            raise ValueError("unknown hash configuration %r" % (hash,))
+        self.hash, self._kind = hash, kinds[hash]
+
     def commit(self, mats):
         """Mmcs::commit.  mats: list of 2-D matrices (torch CUDA tensors stay resident; numpy arrays are
         uploaded).  Returns (root as numpy uint32[8], MerkleTree)."""
@@ -70,8 +95,8 @@ class MerkleTreeMmcs:
         root = np.zeros(8, dtype=np.uint32)
         handle = C.c_void_p()
         torch.cuda.current_stream()  # make sure a context exists
-        _lib.check(L.p3hip_mmcs_commit_dev(ptrs, hs, ws, n, root.ctypes.data_as(C.c_void_p), C.byref(handle),
-                                           _stream_ptr()))
+        _lib.check(L.p3hip_mmcs_commit_hash_dev(self._kind, ptrs, hs, ws, n, root.ctypes.data_as(C.c_void_p),
+                                                C.byref(handle), _stream_ptr()))
         return root, MerkleTree(handle, dmats, root)
 
     def commit_matrix(self, mat):

@@ -1,0 +1,71 @@
+"""GPU parity tests of the Keccak hash configuration (the one the reference itself wires, native/src/fib_air.rs:28-51)
+through the C ABI, bit for bit against oracle/keccak.c, whose permutation is pinned by hashlib (test_oracle_keccak.py)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+P = 0x78000001
+
+
+def test_keccak_f_states(p3, oracle):
+    rng = np.random.default_rng(25)
+    st = rng.integers(0, 2**63, (1000, 25), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, (1000, 25), dtype=np.uint64)
+    st[0] = 0
+    st[1] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    got = p3.keccak_f(st)
+    for i in list(range(8)) + [500, 999]:
+        assert np.array_equal(got[i], oracle.keccak_f(st[i])), i
+    # the zero state's image begins with the well-known lane 0xF1258F7940E1DDE7
+    assert int(got[0][0]) == 0xF1258F7940E1DDE7
+
+
+def test_sha3_256_through_the_gpu_permutation(p3):
+    """FIPS 202 SHA3-256 of a short message with the absorb/pad done here and the permutation on the GPU."""
+    msg = b"Plonky3-mobile fib_air on MI355X"
+    blk = bytearray(msg) + bytes([0x06]) + bytes(136 - len(msg) - 1)
+    blk[-1] |= 0x80
+    st = np.zeros((1, 25), dtype=np.uint64)
+    st[0, :17] = np.frombuffer(bytes(blk), dtype="<u8")
+    out = p3.keccak_f(st)
+    assert out[0].tobytes()[:32] == hashlib.sha3_256(msg).digest()
+
+
+@pytest.mark.parametrize("dims", [[(1, 2)], [(8, 2)], [(1 << 10, 2)], [(1 << 12, 4), (1 << 12, 33)], [(1 << 11, 36)],
+                                  [(1 << 13, 2), (1 << 10, 5), (1 << 10, 70), (4, 3), (1, 9)], [(1 << 16, 2)],
+                                  [(1 << 9, 35), (1 << 9, 1)]])
+def test_keccak_mmcs_commit_open(p3, oracle, dims):
+    rng = np.random.default_rng(sum(h * w for h, w in dims))
+    mats = [rng.integers(0, P, d, dtype=np.uint32) for d in dims]
+    mm = p3.MerkleTreeMmcs(hash="keccak")
+    root, tree = mm.commit(mats)
+    oroot, otree = oracle.mmcs_commit(mats, oracle.HASH_KECCAK)
+    assert np.array_equal(root, oroot)
+    for gl, ol in zip(tree.digest_layers(), otree.layers()):
+        assert np.array_equal(gl, ol)
+    maxh = max(h for h, _ in dims)
+    for index in sorted({0, maxh - 1, maxh // 3, (5 * maxh) // 7}):
+        rows, path = mm.open_batch(index, tree)
+        orows, opath = otree.open_batch(index)
+        assert np.array_equal(np.concatenate(rows) if rows else np.zeros(0, np.uint32), orows)
+        assert np.array_equal(path, opath)
+        assert oracle.mmcs_verify_batch(root, dims, index, orows, path, oracle.HASH_KECCAK)
+    tree.free()
+
+
+def test_keccak_tree_of_the_fib_air_lde(p3, oracle):
+    """The commitment the reference's config would make over the fib_air trace LDE (non-hiding): 2^16-row trace,
+    blowup 2, committed in bit-reversed order; root and a few openings against the oracle."""
+    n = 1 << 16
+    trace = p3.generate_trace_rows(0, 1, n)
+    lde = p3.GpuDft.with_backend(p3.BackendKind.Hip).coset_lde_batch(trace, 1, p3.GENERATOR_MONTY, bit_reversed_out=True)
+    mm = p3.MerkleTreeMmcs(hash="keccak")
+    root, tree = mm.commit([lde])
+    host = oracle.coset_lde_batch(oracle.generate_trace_rows(0, 1, n), 1, p3.GENERATOR_MONTY, True)
+    oroot, _ = oracle.mmcs_commit([host], oracle.HASH_KECCAK)
+    assert np.array_equal(root, oroot)
+    rows, path = mm.open_batch(12345, tree)
+    assert oracle.mmcs_verify_batch(root, [(2 * n, 2)], 12345, rows[0], path, oracle.HASH_KECCAK)
+    with pytest.raises(ValueError):
+        p3.MerkleTreeMmcs(hash="sha256")

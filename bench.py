@@ -180,7 +180,8 @@ def main():
         "roofline": {"bound": "hbm", "achieved": roof["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": roof["gbps"] / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "coset_lde_batch = narrow_inv1_kernel + narrow_mid_kernel + narrow_fwd2_kernel (one unit, three launches)", "algorithmic_bytes": roof["bytes"],
-                     "avg_us": roof["avg_us"], "batched_gbps": roof.get("batched_gbps")},
+                     "avg_us": roof["avg_us"], "concurrent_gbps": roof.get("concurrent_gbps"),
+                     "concurrent_streams": roof.get("concurrent_streams")},
         # The kernel that dominates a proof BY TIME is Poseidon2 (12.6 M permutations per 2^20 proof, ~80 % of the GPU
         # time) and it is integer-VALU-bound, which the contract's hbm|mfma roofline cannot express: reported here
         # against the issue ceiling derived from the measured per-instruction rates.

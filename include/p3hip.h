@@ -128,6 +128,9 @@ int p3hip_mmcs_commit(const uint32_t *const *mats, const size_t *heights, const 
 #define P3HIP_HASH_KECCAK 1
 int p3hip_mmcs_commit_hash_dev(int hash, const uint32_t *const *d_mats, const size_t *heights, const size_t *widths,
                                size_t n_mats, uint32_t root_out[8], p3hip_tree_t **tree_out, void *stream);
+/* host-pointer convenience, as p3hip_mmcs_commit */
+int p3hip_mmcs_commit_hash(int hash, const uint32_t *const *mats, const size_t *heights, const size_t *widths,
+                           size_t n_mats, uint32_t root_out[8], p3hip_tree_t **tree_out);
 /* KeccakF::permute_mut on n independent [u64; 25] states in device memory (p3-keccak's KeccakF, fib_air.rs:32) */
 int p3hip_keccak_f_dev(uint64_t *d_states, size_t n, void *stream);
 

@@ -122,15 +122,16 @@ class MerkleTree {  // prover data: device matrices + digest layers owned by the
     p3hip_tree_t* h_ = nullptr;
     std::vector<size_t> widths_;
 };
-class MerkleTreeMmcs {  // Mmcs<BabyBear> with the Poseidon2 hashes (fib_air.rs:40-51 wires the Keccak flavour)
+class MerkleTreeMmcs {  // Mmcs<BabyBear>: Poseidon2 hashes (north_star) or the Keccak ones fib_air.rs:28-51 wires
   public:
+    explicit MerkleTreeMmcs(int hash = P3HIP_HASH_POSEIDON2) : hash_(hash) {}
     std::pair<std::vector<uint32_t>, MerkleTree> commit(const std::vector<RowMajorMatrix>& mats) const {
         std::vector<const uint32_t*> ptrs;
         std::vector<size_t> hs, ws;
         for (auto& m : mats) { ptrs.push_back(m.values.data()); hs.push_back(m.height()); ws.push_back(m.width); }
         std::vector<uint32_t> root(8);
         MerkleTree t;
-        check(p3hip_mmcs_commit(ptrs.data(), hs.data(), ws.data(), mats.size(), root.data(), &t.h_));
+        check(p3hip_mmcs_commit_hash(hash_, ptrs.data(), hs.data(), ws.data(), mats.size(), root.data(), &t.h_));
         t.widths_ = ws;
         return {std::move(root), std::move(t)};
     }
@@ -146,6 +147,9 @@ class MerkleTreeMmcs {  // Mmcs<BabyBear> with the Poseidon2 hashes (fib_air.rs:
         path.resize(t.log_max_height() * 8);
         return {std::move(out), std::move(path)};
     }
+
+  private:
+    int hash_;
 };
 
 struct FriParameters {  // p3_fri::FriParameters; defaults = create_benchmark_fri_params

@@ -151,16 +151,51 @@ class FibAirJob:
         ms = self._time(run, reps)
         nbytes = 4 * self.n * 2 * (1 + (1 << self.log_blowup))
         res = {"bytes": nbytes, "avg_us": ms * 1e3, "gbps": nbytes / (ms * 1e-3) / 1e9}
-        # same unit over a wide batch (64 traces side by side = 2^h x 128): out of the L2/Infinity-Cache regime
-        wide = torch.randint(0, 0x78000001, (self.n, 128), dtype=torch.int32, device="cuda")
-        wout = torch.empty((self.n << self.log_blowup, 128), dtype=torch.int32, device="cuda")
-
-        def run_wide():
-            _lib.check(L.p3hip_coset_lde_batch_bb31_dev(C.c_void_p(wide.data_ptr()), C.c_void_p(wout.data_ptr()),
-                                                        self.n, 128, self.log_blowup, GENERATOR_MONTY, 1, _stream_ptr()))
-        wms = self._time(run_wide, max(3, reps // 4))
-        res["batched_gbps"] = 64 * nbytes / (wms * 1e-3) / 1e9
+        # the same unit the way the proving loop runs it: `threads` independent LDEs in flight at once, one per host
+        # thread, each on its own stream and per-thread context (own scratch), timed wall-clock around all of them
+        res["concurrent_gbps"], res["concurrent_streams"] = self._concurrent_lde(nbytes), self.threads
         return res
+
+    def _concurrent_lde(self, nbytes, reps=40):
+        L = _lib.lib()
+        go, done = threading.Barrier(self.threads + 1), threading.Barrier(self.threads + 1)
+        errors = []
+
+        def worker():
+            try:
+                torch.cuda.set_device(self.device)
+                st = torch.cuda.Stream()
+                with torch.cuda.stream(st):
+                    trace = generate_trace_rows(0, 1, self.n)
+                    out = torch.empty((self.n << self.log_blowup, 2), dtype=torch.int32, device="cuda")
+
+                    def run():
+                        _lib.check(L.p3hip_coset_lde_batch_bb31_dev(C.c_void_p(trace.data_ptr()), C.c_void_p(out.data_ptr()),
+                                                                    self.n, 2, self.log_blowup, GENERATOR_MONTY, 1,
+                                                                    C.c_void_p(st.cuda_stream)))
+                    run()
+                    st.synchronize()
+                    go.wait()
+                    for _ in range(reps):
+                        run()
+                    st.synchronize()
+            except Exception as e:  # pragma: no cover
+                errors.append(e)
+                go.abort()
+            done.wait()
+
+        ths = [threading.Thread(target=worker, daemon=True) for _ in range(self.threads)]
+        for t in ths:
+            t.start()
+        go.wait()
+        t0 = time.perf_counter()
+        done.wait()
+        dt = time.perf_counter() - t0
+        for t in ths:
+            t.join()
+        if errors:
+            raise errors[0]
+        return self.threads * reps * nbytes / dt / 1e9
 
     def poseidon2_rate(self, reps=5):
         """Poseidon2 permutations/s of the one-state-per-lane kernel (the dominant kernel of a proof by time),

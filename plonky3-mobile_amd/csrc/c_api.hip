@@ -312,6 +312,10 @@ void p3hip_mmcs_free(p3hip_tree_t* tree) {
 }
 int p3hip_mmcs_commit(const uint32_t* const* mats, const size_t* heights, const size_t* widths, size_t n_mats,
                       uint32_t root_out[8], p3hip_tree_t** tree_out) {
+    return p3hip_mmcs_commit_hash(HASH_POSEIDON2, mats, heights, widths, n_mats, root_out, tree_out);
+}
+int p3hip_mmcs_commit_hash(int hash, const uint32_t* const* mats, const size_t* heights, const size_t* widths, size_t n_mats,
+                           uint32_t root_out[8], p3hip_tree_t** tree_out) {
     return guarded([&]() -> int {
         if (!mats || !heights || !widths || !n_mats || !root_out || !tree_out)
             return fail(ERR_BAD_ARG, "mmcs_commit: null/empty argument");
@@ -329,7 +333,7 @@ int p3hip_mmcs_commit(const uint32_t* const* mats, const size_t* heights, const 
             if (bytes && hipMemcpy(d, mats[i], bytes, hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return fail(ERR_HIP, "hipMemcpy failed"); }
             dptr.push_back((const uint32_t*)d);
         }
-        rc = p3hip_mmcs_commit_dev(dptr.data(), heights, widths, n_mats, root_out, tree_out, nullptr);
+        rc = p3hip_mmcs_commit_hash_dev(hash, dptr.data(), heights, widths, n_mats, root_out, tree_out, nullptr);
         if (rc) { cleanup(); return rc; }
         (*tree_out)->t->owned = owned;
         return OK;

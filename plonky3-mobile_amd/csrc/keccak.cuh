@@ -1,7 +1,7 @@
 // Keccak-f[1600], one state per lane (25 x u64 = 50 VGPRs), for the hash configuration the reference itself wires
 // into its MMCS (native/src/fib_air.rs:28-38: PaddingFreeSponge<KeccakF, 25, 17, 4>, SerializingHasher,
 // CompressionFunctionFromHasher<_, 2, 4>; p3-keccak 0.4.2 -> tiny-keccak 2.0.2, both absent: FIPS 202 restated).
-// One round is fully unrolled (rho/pi are register renames, rotations are constant v_alignbit pairs, chi is
+// One round is fully unrolled (rho/pi are register renames, rotations are constant v_alignbit_b32 pairs, chi is
 // v_bfi/v_xor), the 24 rounds stay ROLLED so the kernel's code stays inside the instruction cache — the same
 // lesson as the Poseidon2 kernels.
 #pragma once
@@ -22,10 +22,20 @@ __device__ __forceinline__ constexpr unsigned rho(int i) {
     constexpr unsigned R[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
     return R[i];
 }
+// 64-bit rotate by a constant as two v_alignbit_b32 (hipcc otherwise emits 64-bit shifts + or: twice the issue time)
 template <unsigned N>
 __device__ __forceinline__ uint64_t rotl(uint64_t v) {
+    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
     if constexpr (N == 0) return v;
-    else return (v << N) | (v >> (64 - N));
+    else if constexpr (N == 32) return ((uint64_t)lo << 32) | hi;
+    else if constexpr (N < 32) {
+        const uint32_t nh = __builtin_amdgcn_alignbit(hi, lo, 32 - N), nl = __builtin_amdgcn_alignbit(lo, hi, 32 - N);
+        return ((uint64_t)nh << 32) | nl;
+    } else {
+        constexpr unsigned M = N - 32;
+        const uint32_t nh = __builtin_amdgcn_alignbit(lo, hi, 32 - M), nl = __builtin_amdgcn_alignbit(hi, lo, 32 - M);
+        return ((uint64_t)nh << 32) | nl;
+    }
 }
 
 __device__ __forceinline__ void round(uint64_t (&a)[25], uint64_t rc) {

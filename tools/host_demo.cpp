@@ -46,6 +46,12 @@ int main(int argc, char** argv) {
         auto op = mmcs.open_batch(5, ct.second);
         if (op.first[0] != std::vector<uint32_t>(lde.values.begin() + 10, lde.values.begin() + 12) || op.second.size() != 11 * 8) { std::printf("FAIL open\n"); return 5; }
         std::printf("root[0]=%08x path=%zu digests\n", ct.first[0], op.second.size() / 8);
+        // the same commitment under the reference's own Keccak hashes (fib_air.rs:28-38)
+        MerkleTreeMmcs kmmcs(P3HIP_HASH_KECCAK);
+        auto kt = kmmcs.commit({lde});
+        auto kop = kmmcs.open_batch(5, kt.second);
+        if (kt.first == ct.first || kop.first[0] != op.first[0] || kop.second.size() != 11 * 8) { std::printf("FAIL keccak mmcs\n"); return 10; }
+        std::printf("keccak root[0]=%08x\n", kt.first[0]);
         // prover
         FibAirProver prover(argc > 1 ? std::atoi(argv[1]) : 12);
         auto proof = prover.prove(0, 1);

@@ -52,6 +52,23 @@ if "lde" in which:
         y = torch.empty_like(x)
         ms = timeit(lambda: p3._lib.check(L.p3hip_dft_batch_bb31_dev(C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), h, w, sp())), 5)
         print("dft_batch 2^%d x %d: %.1f us, %.1f GB/s algorithmic" % (log_h, w, ms * 1e3, 8 * h * w / ms / 1e6))
+if "keccak" in which or not sys.argv[1:]:
+    n = 1 << 21
+    st = torch.randint(-2**62, 2**62, (n, 25), dtype=torch.int64, device="cuda")
+    ms = timeit(lambda: p3._lib.check(L.p3hip_keccak_f_dev(C.c_void_p(st.data_ptr()), n, sp())))
+    print("keccak-f[1600]: %.1f us for 2^21 states = %.2f Gperm/s, %.1f GB/s" % (ms * 1e3, n / ms / 1e6, 400 * n / ms / 1e6))
+    km = p3.MerkleTreeMmcs(hash="keccak")
+    for log_h, w in [(21, 2), (21, 4), (17, 2633)]:
+        h = 1 << log_h
+        x = torch.randint(0, P, (h, w), dtype=torch.int32, device="cuda")
+
+        def kcommit():
+            _, t = km.commit([x])
+            t.free()
+        ms = timeit(kcommit, 5)
+        perms = h * ((((w + 1) // 2) + 16) // 17) + h - 1
+        print("keccak mmcs commit 2^%d x %d: %.1f us, %.2f Gperm/s, %.1f GB/s algorithmic" % (log_h, w, ms * 1e3, perms / ms / 1e6, (4 * h * w + 32 * (2 * h - 1)) / ms / 1e6))
+        del x
 if "commit" in which:
     mm = p3.MerkleTreeMmcs()
     for log_h, w in [(21, 2), (21, 4), (20, 8), (12, 8), (17, 2633)]:

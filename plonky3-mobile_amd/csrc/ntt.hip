@@ -824,7 +824,7 @@ int lde_fused(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* ds
 template <int B, int LQ, int K>
 int launch_narrow_t(hipStream_t stream, const NarrowArgs& a, uint32_t blocks) {
     // padded tile (17 rows per 16 points) + stage-table prefixes (K2: inverse and forward)
-    constexpr size_t lds = ((size_t)8 * narrow::lds_rows(B) << LQ) + ((size_t)4 << (B - 4)) * (K == 2 ? 2 : 1);
+    constexpr size_t lds = ((size_t)8 * narrow::lds_rows(B) << LQ) * (K == 2 ? NARROW_MID_TILES : 1) + ((size_t)4 << (B - 4)) * (K == 2 ? 2 : 1);
     void (*kern)(NarrowArgs);
     if constexpr (K == 1) kern = narrow_inv1_kernel<B, LQ>;
     else if constexpr (K == 2) kern = narrow_mid_kernel<B, LQ>;

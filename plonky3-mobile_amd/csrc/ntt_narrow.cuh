@@ -26,6 +26,9 @@
 // Experiment switch: compile the 512-thread middle kernels for 4 waves per SIMD (128 VGPRs) so that two workgroups
 // share a CU.  Measured slower (the 2^24 middle pass 586 -> 898 us): the ~55 spilled registers cost more than the
 // second workgroup hides.
+#ifndef NARROW_MID_TILES
+#define NARROW_MID_TILES 2  // LDS tiles of the middle kernel (1 or 2)
+#endif
 #ifndef NARROW_MID_SHARE_CU
 #define NARROW_MID_SHARE_CU 0
 #endif
@@ -130,10 +133,24 @@ __device__ __forceinline__ void stage_block_round1(uint2 (&v)[16], const uint32_
     }
 }
 
+// One or two LDS tiles.  With two, consecutive hand-overs alternate between them and need ONE barrier each (between
+// the writes and the reads): the tile written now was last read two hand-overs ago, and the barrier of the
+// hand-over in between already separates those reads from these writes.  With one tile (a == b) every hand-over
+// also waits, before writing, for the previous one's reads.
+struct Tiles {
+    uint2* a;
+    uint2* b;
+    __device__ __forceinline__ uint2* next() {
+        if (a != b) { uint2* r = a; a = b; b = r; return r; }
+        __syncthreads();
+        return a;
+    }
+};
+
 // registers (window AF) -> LDS -> registers (window AT)
 template <int LQ, int AF, int AT>
-__device__ __forceinline__ void exchange(uint2* tile, uint2 (&v)[16], uint32_t t, uint32_t q) {
-    __syncthreads();
+__device__ __forceinline__ void exchange(Tiles& tiles, uint2 (&v)[16], uint32_t t, uint32_t q) {
+    uint2* tile = tiles.next();
     uint2* wp = tile + lds_base<LQ, AF>(t, q);
 #pragma unroll
     for (uint32_t j = 0; j < 16; j++) wp[lds_joff<LQ>(j << AF)] = v[j];
@@ -146,7 +163,7 @@ __device__ __forceinline__ void exchange(uint2* tile, uint2 (&v)[16], uint32_t t
 // B-stage DIF of the tile: in: v[j] = point pt_of<B-4>(t, j) (natural order); out: v[j] = position pt_of<0>(t, j),
 // which holds frequency rev_B(position).  twl: stage table in LDS (stages below B-4 at least).
 template <int B, int LQ>
-__device__ __forceinline__ void dif_rounds_after1(uint2 (&v)[16], uint2* tile, const uint32_t* twl, uint32_t t, uint32_t q) {
+__device__ __forceinline__ void dif_rounds_after1(uint2 (&v)[16], Tiles& tile, const uint32_t* twl, uint32_t t, uint32_t q) {
     constexpr int A1 = B - 4, A2 = B > 8 ? B - 8 : 0;
     exchange<LQ, A1, A2>(tile, v, t, q);
     stage_block<A2, A1, A2>(v, twl, t);
@@ -156,15 +173,15 @@ __device__ __forceinline__ void dif_rounds_after1(uint2 (&v)[16], uint2* tile, c
     }
 }
 template <int B, int LQ>
-__device__ __forceinline__ void dif_rounds(uint2 (&v)[16], uint2* tile, const uint32_t (&w1)[15], const uint32_t* twl, uint32_t t, uint32_t q) {
+__device__ __forceinline__ void dif_rounds(uint2 (&v)[16], Tiles& tile, const uint32_t (&w1)[15], const uint32_t* twl, uint32_t t, uint32_t q) {
     stage_block_round1(v, w1);
     dif_rounds_after1<B, LQ>(v, tile, twl, t, q);
 }
 // registers in final layout (position pt_of<0>) -> LDS row = frequency rev_B(position) = (rev4(j) << (B-4)) | rev(t)
 // -> registers in the first layout (row pt_of<B-4>): natural frequency order, 16 consecutive rows per 16 lanes.
 template <int B, int LQ>
-__device__ __forceinline__ void to_natural(uint2* tile, uint2 (&v)[16], uint32_t t, uint32_t q) {
-    __syncthreads();
+__device__ __forceinline__ void to_natural(Tiles& tiles, uint2 (&v)[16], uint32_t t, uint32_t q) {
+    uint2* tile = tiles.next();
     const uint32_t rt = rev_bits(t, B - 4);
     uint2* wp = tile + (((rt + (rt >> 4)) << LQ) + q);
 #pragma unroll
@@ -176,7 +193,7 @@ __device__ __forceinline__ void to_natural(uint2* tile, uint2 (&v)[16], uint32_t
 }
 // same hand-over without the bit reversal (K3: position order is already the wanted order)
 template <int B, int LQ>
-__device__ __forceinline__ void to_rows(uint2* tile, uint2 (&v)[16], uint32_t t, uint32_t q) {
+__device__ __forceinline__ void to_rows(Tiles& tile, uint2 (&v)[16], uint32_t t, uint32_t q) {
     exchange<LQ, 0, B - 4>(tile, v, t, q);
 }
 
@@ -216,7 +233,7 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow_inv1_kernel(NarrowAr
     using namespace narrow;
     constexpr uint32_t NQ = 1u << LQ, NTH = 1u << (B - 4 + LQ);
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint2* tile = reinterpret_cast<uint2*>(smem);
+    Tiles tile{reinterpret_cast<uint2*>(smem), reinterpret_cast<uint2*>(smem)};
     uint32_t* twl = smem + (2u * lds_rows(B) << LQ);                                // stages below B-4: 2^(B-4) - 1 words
     const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> LQ;
     const uint32_t s = tile_of_block<LQ>(blockIdx.x, a.xcd_remap) * NQ + q;  // 8-byte slot within a row group of N2 rows
@@ -248,8 +265,9 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ), (B - 4 + LQ >= 9 && NARROW_
     constexpr uint32_t NQ = 1u << LQ, NTH = 1u << (B - 4 + LQ);
     constexpr bool LEAN = NTH >= 512;  // 128 VGPRs per lane: rebuild the output ladder per coset
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint2* tile = reinterpret_cast<uint2*>(smem);
-    uint32_t* twl_i = smem + (2u * lds_rows(B) << LQ);   // inverse stages below B-4
+    // two tiles (one barrier per hand-over): the 15 hand-overs of a blowup-4 middle pass are this kernel's stalls
+    Tiles tile{reinterpret_cast<uint2*>(smem), reinterpret_cast<uint2*>(smem) + (NARROW_MID_TILES - 1) * (lds_rows(B) << LQ)};
+    uint32_t* twl_i = smem + (NARROW_MID_TILES * 2u * lds_rows(B) << LQ);   // inverse stages below B-4
     uint32_t* twl_f = twl_i + (1u << (B - 4)); // forward stages below B-4
     const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> LQ;
     const uint32_t s = tile_of_block<LQ>(blockIdx.x, a.xcd_remap) * NQ + q;  // slot within a group of N1 rows
@@ -303,7 +321,7 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow_fwd2_kernel(NarrowAr
     using namespace narrow;
     constexpr uint32_t NQ = 1u << LQ, NTH = 1u << (B - 4 + LQ);
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint2* tile = reinterpret_cast<uint2*>(smem);
+    Tiles tile{reinterpret_cast<uint2*>(smem), reinterpret_cast<uint2*>(smem)};
     uint32_t* twl = smem + (2u * lds_rows(B) << LQ);
     const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> LQ;
     const uint32_t s = blockIdx.x * NQ + q;

@@ -1,4 +1,4 @@
-// Three-launch coset LDE for NARROW matrices (W = 2, 4 or 8 columns: the fib_air trace and quotient shapes).
+// Three-launch coset LDE for NARROW matrices (W = 2, 4, 8 or 16 columns: the fib_air trace and quotient shapes).
 //
 // The general plans (ntt.hip / ntt_fast.cuh) move one 32-bit word per lane and cut 2^n rows into three 6-8 stage
 // digits per direction: five launches for 2^20 -> 2^21, every one re-reading and re-writing the matrix.  Here the

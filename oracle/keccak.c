@@ -82,3 +82,23 @@ void p3o_keccak_compress(const uint32_t l[8], const uint32_t r[8], uint32_t out[
     p3o_keccak_f(st);
     for (int k = 0; k < 4; k++) { out[2 * k] = (uint32_t)st[k]; out[2 * k + 1] = (uint32_t)(st[k] >> 32); }
 }
+
+/* Keccak256Hash::hash_iter over bytes (p3-keccak: tiny-keccak's Keccak::v256 = ORIGINAL Keccak padding 0x01,
+ * rate 136, 32-byte digest) — the byte hash of the reference's challenger (fib_air.rs:29-30,53). */
+void p3o_keccak256(const uint8_t *in, size_t n, uint8_t out[32]) {
+    uint64_t st[25] = {0};
+    uint8_t blk[136];
+    size_t off = 0;
+    for (;;) {
+        size_t take = n - off < 136 ? n - off : 136;
+        memset(blk, 0, 136);
+        memcpy(blk, in + off, take);
+        int last = take < 136;
+        if (last) { blk[take] ^= 0x01; blk[135] ^= 0x80; }
+        for (int i = 0; i < 17; i++) { uint64_t w; memcpy(&w, blk + 8 * i, 8); st[i] ^= w; }
+        p3o_keccak_f(st);
+        off += take;
+        if (last) break;
+    }
+    memcpy(out, st, 32);
+}

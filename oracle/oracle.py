@@ -254,13 +254,15 @@ class FriParams:
         return (self.log_blowup, self.log_final_poly_len, self.num_queries, self.proof_of_work_bits)
 
 
-def prove_fib_air(a, b, log_n, params=None):
+def prove_fib_air(a, b, log_n, params=None, hash=HASH_POSEIDON2):
+    """hash=HASH_KECCAK: the reference's own hash configuration (Keccak MMCS + SerializingChallenger32 over a
+    Keccak-256 HashChallenger, fib_air.rs:28-53), non-hiding."""
     params = params or FriParams()
     out = C.POINTER(C.c_uint8)()
     n = C.c_size_t()
     L = lib()
-    rc = L.p3o_prove_fib_air(C.c_uint64(a), C.c_uint64(b), C.c_uint(log_n), *[C.c_uint(v) for v in params.astuple()],
-                             C.byref(out), C.byref(n))
+    rc = L.p3o_prove_fib_air_hash(C.c_int(hash), C.c_uint64(a), C.c_uint64(b), C.c_uint(log_n),
+                                  *[C.c_uint(v) for v in params.astuple()], C.byref(out), C.byref(n))
     if rc:
         raise ValueError("oracle prove_fib_air: bad parameters")
     data = C.string_at(out, n.value)
@@ -268,12 +270,19 @@ def prove_fib_air(a, b, log_n, params=None):
     return data
 
 
-def verify_fib_air(proof, a, b, x, log_n, params=None):
+def verify_fib_air(proof, a, b, x, log_n, params=None, hash=HASH_POSEIDON2):
     """0 = accept, otherwise the code of the failed check."""
     params = params or FriParams()
     buf = (C.c_uint8 * len(proof)).from_buffer_copy(proof)
-    return lib().p3o_verify_fib_air(buf, C.c_size_t(len(proof)), C.c_uint64(a), C.c_uint64(b), C.c_uint64(x),
-                                    C.c_uint(log_n), *[C.c_uint(v) for v in params.astuple()])
+    return lib().p3o_verify_fib_air_hash(C.c_int(hash), buf, C.c_size_t(len(proof)), C.c_uint64(a), C.c_uint64(b),
+                                         C.c_uint64(x), C.c_uint(log_n), *[C.c_uint(v) for v in params.astuple()])
+
+
+def keccak256(data):
+    out = (C.c_uint8 * 32)()
+    buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(bytes(data) or b"\0")
+    lib().p3o_keccak256(buf, C.c_size_t(len(data)), out)
+    return bytes(out)
 
 
 def fib_public_x(a, b, n):

@@ -73,12 +73,19 @@ void p3o_keccak_f(uint64_t state[25]);
 void p3o_keccak_sponge_u64(const uint64_t *items, size_t n, uint64_t out[4]);
 void p3o_keccak_hash_row(const uint32_t *items, size_t n, uint32_t out[8]);
 void p3o_keccak_compress(const uint32_t left[8], const uint32_t right[8], uint32_t out[8]);
+void p3o_keccak256(const uint8_t *in, size_t n, uint8_t out[32]);
 
 /* ---- stark.c: fib_air prover / verifier (uni-stark + two-adic FRI PCS + duplex challenger) ---- */
 int p3o_prove_fib_air(uint64_t a, uint64_t b, unsigned log_n, unsigned log_blowup, unsigned log_final_poly_len,
                       unsigned num_queries, unsigned pow_bits, uint8_t **out, size_t *out_len);
 int p3o_verify_fib_air(const uint8_t *proof, size_t len, uint64_t a, uint64_t b, uint64_t x_pub, unsigned log_n,
                        unsigned log_blowup, unsigned log_final_poly_len, unsigned num_queries, unsigned pow_bits);
+/* hash = 0: the Poseidon2 configuration above; 1: the reference's own hashes (fib_air.rs:28-53, non-hiding):
+ * Keccak MMCS (keccak.c) + SerializingChallenger32<BabyBear, HashChallenger<u8, Keccak256Hash, 32>> */
+int p3o_prove_fib_air_hash(int hash, uint64_t a, uint64_t b, unsigned log_n, unsigned log_blowup, unsigned log_final_poly_len,
+                           unsigned num_queries, unsigned pow_bits, uint8_t **out, size_t *out_len);
+int p3o_verify_fib_air_hash(int hash, const uint8_t *proof, size_t len, uint64_t a, uint64_t b, uint64_t x_pub, unsigned log_n,
+                            unsigned log_blowup, unsigned log_final_poly_len, unsigned num_queries, unsigned pow_bits);
 void p3o_free(void *p);
 
 #ifdef __cplusplus

@@ -16,13 +16,24 @@
 #include <string.h>
 
 /* ------------------------------------------------------------------ challenger */
-/* DuplexChallenger<F, Perm, WIDTH 16, RATE 8>: observe buffers up to RATE inputs then duplexes
- * (overwrite, permute, refill output with state[0..8]); sample pops from the BACK of the output. */
+/* kind 0: DuplexChallenger<F, Perm, WIDTH 16, RATE 8>: observe buffers up to RATE inputs then duplexes
+ * (overwrite, permute, refill output with state[0..8]); sample pops from the BACK of the output.
+ * kind 1: SerializingChallenger32<BabyBear, HashChallenger<u8, Keccak256Hash, 32>> (fib_air.rs:53,66)
+ * [UPSTREAM-RECALL, p3-challenger 0.4.2 absent]: HashChallenger keeps an input byte buffer and a 32-byte output
+ * buffer; observe clears the output and appends; sample pops output bytes from the BACK, flushing first when it
+ * is empty (output = Keccak256(input), input := output as the chaining value).  The serialising wrapper observes a
+ * field element as the 4 little-endian bytes of its unique u32 (the Montgomery word), a [u64; 4] digest as its 32
+ * little-endian bytes, and samples a base element by rejection: u32 from 4 sampled bytes, masked to 31 bits,
+ * accepted when below P. */
 typedef struct {
+    int kind;
     uint32_t state[16], in[8], out[8];
     int n_in, n_out;
+    uint8_t *ibuf; size_t ilen, icap;
+    uint8_t obuf[32]; int n_obuf;
 } chal_t;
-static void chal_init(chal_t *c) { memset(c, 0, sizeof *c); }
+static void chal_init(chal_t *c, int kind) { memset(c, 0, sizeof *c); c->kind = kind; }
+static void chal_free(chal_t *c) { free(c->ibuf); c->ibuf = NULL; }
 static void chal_duplex(chal_t *c) {
     for (int i = 0; i < c->n_in; i++) c->state[i] = c->in[i];
     c->n_in = 0;
@@ -30,14 +41,42 @@ static void chal_duplex(chal_t *c) {
     memcpy(c->out, c->state, 32);
     c->n_out = 8;
 }
+static void hc_observe_bytes(chal_t *c, const uint8_t *p, size_t n) {
+    c->n_obuf = 0;
+    if (c->ilen + n > c->icap) { c->icap = (c->ilen + n) * 2 + 64; c->ibuf = realloc(c->ibuf, c->icap); }
+    memcpy(c->ibuf + c->ilen, p, n);
+    c->ilen += n;
+}
+static void hc_flush(chal_t *c) {
+    p3o_keccak256(c->ibuf, c->ilen, c->obuf);
+    c->n_obuf = 32;
+    c->ilen = 0;
+    hc_observe_bytes(c, c->obuf, 32);  /* chaining value */
+    c->n_obuf = 32;                    /* (the append above is not an observation: the output stays valid) */
+}
+static uint8_t hc_sample_byte(chal_t *c) {
+    if (!c->n_obuf) hc_flush(c);
+    return c->obuf[--c->n_obuf];
+}
 static void chal_observe(chal_t *c, uint32_t v) {
+    if (c->kind) { uint8_t le[4] = {(uint8_t)v, (uint8_t)(v >> 8), (uint8_t)(v >> 16), (uint8_t)(v >> 24)}; hc_observe_bytes(c, le, 4); return; }
     c->n_out = 0;
     c->in[c->n_in++] = v;
     if (c->n_in == 8) chal_duplex(c);
 }
 static void chal_observe_n(chal_t *c, const uint32_t *v, size_t n) { for (size_t i = 0; i < n; i++) chal_observe(c, v[i]); }
+/* a commitment: 8 field elements (kind 0) or [u64; 4] = the same 32 little-endian bytes (kind 1) */
+static void chal_observe_digest(chal_t *c, const uint32_t d[8]) { chal_observe_n(c, d, 8); }
 static void chal_observe_ext(chal_t *c, bb4_t v) { chal_observe_n(c, v.c, 4); }
 static uint32_t chal_sample(chal_t *c) {
+    if (c->kind) {
+        for (;;) {
+            uint32_t v = 0;
+            for (int i = 0; i < 4; i++) v |= (uint32_t)hc_sample_byte(c) << (8 * i);
+            v &= 0x7fffffffu;
+            if (v < BB_P) return bb_to_monty(v);
+        }
+    }
     if (c->n_in || !c->n_out) chal_duplex(c);
     return c->out[--c->n_out];
 }
@@ -50,7 +89,10 @@ static int chal_check_witness(chal_t *c, unsigned bits, uint32_t w) { chal_obser
 static uint32_t chal_grind(chal_t *c, unsigned bits) {
     for (uint32_t i = 0; i < BB_P; i++) {
         chal_t t = *c;
-        if (chal_check_witness(&t, bits, bb_to_monty(i))) { chal_check_witness(c, bits, bb_to_monty(i)); return bb_to_monty(i); }
+        if (c->kind) { t.ibuf = malloc(c->ilen + 64); t.icap = c->ilen + 64; memcpy(t.ibuf, c->ibuf, c->ilen); }
+        int ok = chal_check_witness(&t, bits, bb_to_monty(i));
+        if (c->kind) free(t.ibuf);
+        if (ok) { chal_check_witness(c, bits, bb_to_monty(i)); return bb_to_monty(i); }
     }
     return 0;
 }
@@ -127,8 +169,9 @@ static void fold_matrix(const bb4_t *in, size_t len, bb4_t beta, bb4_t *out) {
 static void put_path(buf_t *b, const uint32_t *path, size_t n) { put_u32(b, (uint32_t)n); put_words(b, path, n * 8); }
 
 /* p3_uni_stark::prove for FibonacciAir.  Returns malloc'd proof bytes. */
-int p3o_prove_fib_air(uint64_t a, uint64_t b, unsigned log_n, unsigned log_blowup, unsigned log_final_poly_len,
-                      unsigned num_queries, unsigned pow_bits, uint8_t **out, size_t *out_len) {
+int p3o_prove_fib_air_hash(int hash, uint64_t a, uint64_t b, unsigned log_n, unsigned log_blowup, unsigned log_final_poly_len,
+                           unsigned num_queries, unsigned pow_bits, uint8_t **out, size_t *out_len) {
+    if (hash != 0 && hash != 1) return -1;
     if (log_n < 1 || log_blowup < 1 || log_n + log_blowup > BB_TWO_ADICITY || log_final_poly_len > log_n) return -1;
     /* p3_fri::prover::prove: if log_final_poly_len > 0, log_min_height > log_final_poly_len + log_blowup */
     if (log_final_poly_len > 0 && log_final_poly_len >= log_n) return -1;
@@ -146,11 +189,11 @@ int p3o_prove_fib_air(uint64_t a, uint64_t b, unsigned log_n, unsigned log_blowu
     p3o_coset_lde_batch(trace, lde_t, n, 2, log_blowup, gen, 1);
     uint32_t root_t[8];
     const uint32_t *mp[1] = {lde_t}; size_t hh[1] = {big}, ww[1] = {2};
-    p3o_tree_t *tree_t = p3o_mmcs_commit(mp, hh, ww, 1, root_t);
-    chal_t ch; chal_init(&ch);
+    p3o_tree_t *tree_t = p3o_mmcs_commit_kind(hash, mp, hh, ww, 1, root_t);
+    chal_t ch; chal_init(&ch, hash);
     chal_observe(&ch, bb_to_monty(log_n)); /* log_ext_degree */
     chal_observe(&ch, bb_to_monty(log_n)); /* log_degree */
-    chal_observe_n(&ch, root_t, 8);
+    chal_observe_digest(&ch, root_t);
     chal_observe_n(&ch, pis, 3);
     bb4_t alpha = chal_sample_ext(&ch);
     /* quotient_values on the quotient domain GENERATOR*<g_n> (quotient degree 1) */
@@ -177,8 +220,8 @@ int p3o_prove_fib_air(uint64_t a, uint64_t b, unsigned log_n, unsigned log_blowu
     p3o_coset_lde_batch(qflat, lde_q, n, 4, log_blowup, BB_ONE, 1);
     uint32_t root_q[8];
     mp[0] = lde_q; ww[0] = 4;
-    p3o_tree_t *tree_q = p3o_mmcs_commit(mp, hh, ww, 1, root_q);
-    chal_observe_n(&ch, root_q, 8);
+    p3o_tree_t *tree_q = p3o_mmcs_commit_kind(hash, mp, hh, ww, 1, root_q);
+    chal_observe_digest(&ch, root_q);
     bb4_t zeta = chal_sample_ext(&ch);
     bb4_t zeta_next = bb4_scale(zeta, bb_two_adic_generator(log_n));
     /* pcs.open: opened values (observed), then the batching challenge */
@@ -223,8 +266,8 @@ int p3o_prove_fib_air(uint64_t a, uint64_t b, unsigned log_n, unsigned log_blowu
     for (unsigned r = 0; r < n_rounds; r++) {
         flayers[r] = folded;
         mp[0] = (const uint32_t *)folded; hh[0] = flen / 2; ww[0] = 8; /* ExtensionMmcs: width-2 ext rows flattened */
-        ftrees[r] = p3o_mmcs_commit(mp, hh, ww, 1, froots[r]);
-        chal_observe_n(&ch, froots[r], 8);
+        ftrees[r] = p3o_mmcs_commit_kind(hash, mp, hh, ww, 1, froots[r]);
+        chal_observe_digest(&ch, froots[r]);
         bb4_t beta = chal_sample_ext(&ch);
         bb4_t *next = malloc((flen / 2) * sizeof(bb4_t));
         fold_matrix(folded, flen, beta, next);
@@ -269,10 +312,14 @@ int p3o_prove_fib_air(uint64_t a, uint64_t b, unsigned log_n, unsigned log_blowu
     for (unsigned r = 0; r < n_rounds; r++) { p3o_mmcs_free(ftrees[r]); if (r) free(flayers[r]); }
     if (n_rounds) free(folded);
     free(ro); free(ftrees); free(flayers); free(froots); free(fpoly); free(path);
-    p3o_mmcs_free(tree_t); p3o_mmcs_free(tree_q);
+    p3o_mmcs_free(tree_t); p3o_mmcs_free(tree_q); chal_free(&ch);
     free(trace); free(lde_t); free(qflat); free(lde_q);
     *out = pf.p; *out_len = pf.len;
     return 0;
+}
+int p3o_prove_fib_air(uint64_t a, uint64_t b, unsigned log_n, unsigned log_blowup, unsigned log_final_poly_len,
+                      unsigned num_queries, unsigned pow_bits, uint8_t **out, size_t *out_len) {
+    return p3o_prove_fib_air_hash(0, a, b, log_n, log_blowup, log_final_poly_len, num_queries, pow_bits, out, out_len);
 }
 void p3o_free(void *p) { free(p); }
 
@@ -281,11 +328,17 @@ typedef struct { const uint8_t *p; size_t len, pos; int bad; } rd_t;
 static uint32_t get_u32(rd_t *r) { uint32_t v = 0; if (r->pos + 4 > r->len) { r->bad = 1; return 0; } memcpy(&v, r->p + r->pos, 4); r->pos += 4; return v; }
 static void get_words(rd_t *r, uint32_t *w, size_t n) { for (size_t i = 0; i < n; i++) { w[i] = get_u32(r); if (w[i] >= BB_P) r->bad = 1; } }
 static bb4_t get_ext(rd_t *r) { bb4_t v; get_words(r, v.c, 4); return v; }
+/* n digests: field elements below P (Poseidon2) or raw [u64; 4] bytes (Keccak) */
+static void get_digests(rd_t *r, int hash, uint32_t *w, size_t n) {
+    if (!hash) { get_words(r, w, 8 * n); return; }
+    for (size_t i = 0; i < 8 * n; i++) w[i] = get_u32(r);
+}
 
 /* p3_uni_stark::verify + TwoAdicFriPcs::verify + p3_fri::verifier for FibonacciAir.
  * 0 = accept; positive codes name the failed check. */
-int p3o_verify_fib_air(const uint8_t *proof, size_t len, uint64_t a, uint64_t b, uint64_t x_pub, unsigned log_n,
-                       unsigned log_blowup, unsigned log_final_poly_len, unsigned num_queries, unsigned pow_bits) {
+int p3o_verify_fib_air_hash(int hash, const uint8_t *proof, size_t len, uint64_t a, uint64_t b, uint64_t x_pub, unsigned log_n,
+                            unsigned log_blowup, unsigned log_final_poly_len, unsigned num_queries, unsigned pow_bits) {
+    if (hash != 0 && hash != 1) return -1;
     rd_t rd = {proof, len, 0, 0};
     const unsigned log_big = log_n + log_blowup;
     const size_t n = (size_t)1 << log_n;
@@ -293,7 +346,7 @@ int p3o_verify_fib_air(const uint8_t *proof, size_t len, uint64_t a, uint64_t b,
     if (get_u32(&rd) != 0x42463350u || get_u32(&rd) != 1) return 1;
     if (get_u32(&rd) != log_n) return 2;
     uint32_t root_t[8], root_q[8];
-    get_words(&rd, root_t, 8); get_words(&rd, root_q, 8);
+    get_digests(&rd, hash, root_t, 1); get_digests(&rd, hash, root_q, 1);
     bb4_t t_loc[2], t_nxt[2], q_z[4];
     if (get_u32(&rd) != 2) return 3;
     for (int i = 0; i < 2; i++) t_loc[i] = get_ext(&rd);
@@ -303,11 +356,11 @@ int p3o_verify_fib_air(const uint8_t *proof, size_t len, uint64_t a, uint64_t b,
     for (int i = 0; i < 4; i++) q_z[i] = get_ext(&rd);
     if (rd.bad) return 4;
     uint32_t pis[3] = {bb_to_monty((uint32_t)(a % BB_P)), bb_to_monty((uint32_t)(b % BB_P)), bb_to_monty((uint32_t)(x_pub % BB_P))};
-    chal_t ch; chal_init(&ch);
+    chal_t ch; chal_init(&ch, hash);
     chal_observe(&ch, bb_to_monty(log_n)); chal_observe(&ch, bb_to_monty(log_n));
-    chal_observe_n(&ch, root_t, 8); chal_observe_n(&ch, pis, 3);
+    chal_observe_digest(&ch, root_t); chal_observe_n(&ch, pis, 3);
     bb4_t alpha = chal_sample_ext(&ch);
-    chal_observe_n(&ch, root_q, 8);
+    chal_observe_digest(&ch, root_q);
     bb4_t zeta = chal_sample_ext(&ch);
     uint32_t g_n = bb_two_adic_generator(log_n);
     bb4_t zeta_next = bb4_scale(zeta, g_n);
@@ -326,7 +379,7 @@ int p3o_verify_fib_air(const uint8_t *proof, size_t len, uint64_t a, uint64_t b,
       /* quotient(zeta) = sum_e basis_e * chunk[e]; basis_e = x^e */
       bb4_t quot = bb4_zero();
       for (int e = 0; e < 4; e++) { bb4_t be = bb4_zero(); be.c[e] = BB_ONE; quot = bb4_add(quot, bb4_mul(be, q_z[e])); }
-      if (!bb4_eq(bb4_mul(folded, bb4_inv(zh)), quot)) return 10; /* OodEvaluationMismatch */ }
+      if (!bb4_eq(bb4_mul(folded, bb4_inv(zh)), quot)) { chal_free(&ch); return 10; } /* OodEvaluationMismatch */ }
     /* pcs.verify */
     for (int i = 0; i < 2; i++) chal_observe_ext(&ch, t_loc[i]);
     for (int i = 0; i < 2; i++) chal_observe_ext(&ch, t_nxt[i]);
@@ -334,12 +387,12 @@ int p3o_verify_fib_air(const uint8_t *proof, size_t len, uint64_t a, uint64_t b,
     bb4_t al = chal_sample_ext(&ch);
     bb4_t alp[8]; alp[0] = bb4_one(); for (int k = 1; k < 8; k++) alp[k] = bb4_mul(alp[k - 1], al);
     unsigned n_rounds = get_u32(&rd);
-    if (rd.bad || n_rounds != log_big - log_blowup - log_final_poly_len) return 5;
+    if (rd.bad || n_rounds != log_big - log_blowup - log_final_poly_len) { chal_free(&ch); return 5; }
     uint32_t (*froots)[8] = malloc((n_rounds + 1) * 32);
     bb4_t *betas = malloc((n_rounds + 1) * sizeof(bb4_t));
-    for (unsigned r = 0; r < n_rounds; r++) get_words(&rd, froots[r], 8);
-    for (unsigned r = 0; r < n_rounds; r++) { chal_observe_n(&ch, froots[r], 8); betas[r] = chal_sample_ext(&ch); }
-    if (get_u32(&rd) != num_queries) { free(froots); free(betas); return 6; }
+    for (unsigned r = 0; r < n_rounds; r++) get_digests(&rd, hash, froots[r], 1);
+    for (unsigned r = 0; r < n_rounds; r++) { chal_observe_digest(&ch, froots[r]); betas[r] = chal_sample_ext(&ch); }
+    if (get_u32(&rd) != num_queries) { free(froots); free(betas); chal_free(&ch); return 6; }
     /* the final polynomial and the witness sit after the queries: find them first */
     size_t qstart = rd.pos;
     for (unsigned q = 0; q < num_queries && !rd.bad; q++) {
@@ -349,7 +402,7 @@ int p3o_verify_fib_air(const uint8_t *proof, size_t len, uint64_t a, uint64_t b,
         for (uint32_t r = 0; r < nr && !rd.bad; r++) { rd.pos += 16; uint32_t pl = get_u32(&rd); rd.pos += 32 * (size_t)pl; }
     }
     uint32_t fpl = get_u32(&rd);
-    if (rd.bad || fpl != (1u << log_final_poly_len)) { free(froots); free(betas); return 7; }
+    if (rd.bad || fpl != (1u << log_final_poly_len)) { free(froots); free(betas); chal_free(&ch); return 7; }
     bb4_t *fpoly = malloc(fpl * sizeof(bb4_t));
     for (uint32_t i = 0; i < fpl; i++) { fpoly[i] = get_ext(&rd); chal_observe_ext(&ch, fpoly[i]); }
     uint32_t witness = get_u32(&rd);
@@ -365,14 +418,14 @@ int p3o_verify_fib_air(const uint8_t *proof, size_t len, uint64_t a, uint64_t b,
         if (get_u32(&rd) != 2) { rc = 12; break; }
         if (get_u32(&rd) != 1 || get_u32(&rd) != 2) { rc = 12; break; }
         get_words(&rd, trow, 2);
-        if (get_u32(&rd) != log_big) { rc = 12; break; } get_words(&rd, path, 8 * (size_t)log_big);
+        if (get_u32(&rd) != log_big) { rc = 12; break; } get_digests(&rd, hash, path, log_big);
         dims_w[0] = 2;
-        if (p3o_mmcs_verify_batch(root_t, dims_h, dims_w, 1, index, trow, path, log_big)) { rc = 13; break; }
+        if (p3o_mmcs_verify_batch_kind(hash, root_t, dims_h, dims_w, 1, index, trow, path, log_big)) { rc = 13; break; }
         if (get_u32(&rd) != 1 || get_u32(&rd) != 4) { rc = 12; break; }
         get_words(&rd, qrow, 4);
-        if (get_u32(&rd) != log_big) { rc = 12; break; } get_words(&rd, path, 8 * (size_t)log_big);
+        if (get_u32(&rd) != log_big) { rc = 12; break; } get_digests(&rd, hash, path, log_big);
         dims_w[0] = 4;
-        if (p3o_mmcs_verify_batch(root_q, dims_h, dims_w, 1, index, qrow, path, log_big)) { rc = 13; break; }
+        if (p3o_mmcs_verify_batch_kind(hash, root_q, dims_h, dims_w, 1, index, qrow, path, log_big)) { rc = 13; break; }
         /* reduced opening at the queried point x = GENERATOR * g_big^bitrev(index) */
         uint32_t xi = bb_mul(gen, bb_pow(bb_two_adic_generator(log_big), rev_bits(index, log_big)));
         bb4_t d0 = bb4_inv(bb4_sub(zeta, bb4_from_base(xi))), d1 = bb4_inv(bb4_sub(zeta_next, bb4_from_base(xi)));
@@ -387,11 +440,11 @@ int p3o_verify_fib_air(const uint8_t *proof, size_t len, uint64_t a, uint64_t b,
             unsigned log_folded_height = log_big - 1 - r;
             bb4_t sib = get_ext(&rd);
             if (get_u32(&rd) != log_folded_height) { rc = 12; break; }
-            get_words(&rd, path, 8 * (size_t)log_folded_height);
+            get_digests(&rd, hash, path, log_folded_height);
             bb4_t ev[2]; ev[idx & 1] = folded; ev[(idx & 1) ^ 1] = sib;
             size_t pair = idx >> 1;
             size_t dh[1] = {(size_t)1 << log_folded_height}, dw[1] = {8};
-            if (p3o_mmcs_verify_batch(froots[r], dh, dw, 1, pair, (const uint32_t *)ev, path, log_folded_height)) { rc = 14; break; }
+            if (p3o_mmcs_verify_batch_kind(hash, froots[r], dh, dw, 1, pair, (const uint32_t *)ev, path, log_folded_height)) { rc = 14; break; }
             /* fold_row: interpolate (s, e0), (-s, e1) at beta, s = g_{h+1}^bitrev(pair) */
             uint32_t s = bb_pow(bb_two_adic_generator(log_folded_height + 1), rev_bits(pair, log_folded_height));
             bb4_t num = bb4_mul(bb4_sub(betas[r], bb4_from_base(s)), bb4_sub(ev[1], ev[0]));
@@ -407,6 +460,11 @@ int p3o_verify_fib_air(const uint8_t *proof, size_t len, uint64_t a, uint64_t b,
         if (!bb4_eq(ev, folded)) rc = 15; /* FinalPolyMismatch */
     }
     if (rd.bad && !rc) rc = 9;
-    free(path); free(fpoly); free(froots); free(betas);
+    free(path); free(fpoly); free(froots); free(betas); chal_free(&ch);
     return rc;
+}
+
+int p3o_verify_fib_air(const uint8_t *proof, size_t len, uint64_t a, uint64_t b, uint64_t x_pub, unsigned log_n,
+                       unsigned log_blowup, unsigned log_final_poly_len, unsigned num_queries, unsigned pow_bits) {
+    return p3o_verify_fib_air_hash(0, proof, len, a, b, x_pub, log_n, log_blowup, log_final_poly_len, num_queries, pow_bits);
 }

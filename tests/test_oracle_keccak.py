@@ -77,3 +77,46 @@ def test_keccak_tree_open_verify(oracle, dims):
             bad = rows.copy()
             bad[0] ^= 1
             assert not oracle.mmcs_verify_batch(root, dims, index, bad, path, oracle.HASH_KECCAK)
+
+
+def test_keccak256_bytes(oracle):
+    rng = np.random.default_rng(256)
+    assert oracle.keccak256(b"").hex() == "c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470"
+    for n in [1, 31, 135, 136, 137, 272, 500]:
+        msg = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert oracle.keccak256(msg) == _sponge_bytes(oracle, msg, 136, 0x01, 32), n
+
+
+@pytest.mark.parametrize("log_n", [1, 3, 6, 9])
+def test_keccak_config_prove_then_verify(oracle, log_n):
+    """fib_air under the reference's own hashes (Keccak MMCS + SerializingChallenger32 / HashChallenger<Keccak256>,
+    fib_air.rs:28-53; non-hiding).  Self-consistency only: the conventions of p3-challenger are recalled, not pinned."""
+    fp = oracle.FriParams(1, 0, 12, 6)
+    K = oracle.HASH_KECCAK
+    proof = oracle.prove_fib_air(0, 1, log_n, fp, hash=K)
+    x = oracle.fib_public_x(0, 1, 1 << log_n)
+    assert oracle.verify_fib_air(proof, 0, 1, x, log_n, fp, hash=K) == 0
+    assert oracle.prove_fib_air(0, 1, log_n, fp, hash=K) == proof
+    assert oracle.verify_fib_air(proof, 0, 1, x + 1, log_n, fp, hash=K) != 0
+    assert oracle.verify_fib_air(proof, 0, 1, x, log_n, fp) != 0          # Poseidon2 verifier on a Keccak proof
+    assert proof != oracle.prove_fib_air(0, 1, log_n, fp)
+    # the reference's instance: n = 8, x = 21 (fib_air.rs:56-57)
+    if log_n == 3:
+        assert x == 21
+
+
+def test_keccak_config_tampering_and_parameters(oracle):
+    K = oracle.HASH_KECCAK
+    fp = oracle.FriParams(1, 0, 3, 4)
+    proof = oracle.prove_fib_air(0, 1, 4, fp, hash=K)
+    x = oracle.fib_public_x(0, 1, 16)
+    words = np.frombuffer(proof, dtype=np.uint32)
+    rng = np.random.default_rng(1)
+    for pos in rng.choice(len(words), size=60, replace=False):
+        bad = words.copy()
+        bad[pos] = (int(bad[pos]) + 1) % 0x78000001
+        assert oracle.verify_fib_air(bad.tobytes(), 0, 1, x, 4, fp, hash=K) != 0, pos
+    for t in [(2, 0, 5, 3), (2, 2, 5, 4), (1, 3, 7, 8)]:
+        fp = oracle.FriParams(*t)
+        proof = oracle.prove_fib_air(5, 8, 7, fp, hash=K)
+        assert oracle.verify_fib_air(proof, 5, 8, oracle.fib_public_x(5, 8, 128), 7, fp, hash=K) == 0

@@ -163,6 +163,14 @@ void p3hip_fib_prover_destroy(p3hip_fib_prover_t *prover);
 int p3hip_verify_fib_air(const uint8_t *proof, size_t len, uint64_t a, uint64_t b, uint64_t x, unsigned log_n,
                          const p3hip_fri_params_t *params);
 
+/* The same prover / verifier under the reference's own hashes (hash = P3HIP_HASH_KECCAK; native/src/fib_air.rs:28-53):
+ * Keccak MMCS + SerializingChallenger32<BabyBear, HashChallenger<u8, Keccak256Hash, 32>>, non-hiding.  Same wire
+ * format; digests are [u64; 4] as 8 little-endian u32 words. */
+int p3hip_fib_prover_create_hash(int hash, unsigned log_n, const p3hip_fri_params_t *params, void *stream, int own_stream,
+                                 p3hip_fib_prover_t **out);
+int p3hip_verify_fib_air_hash(int hash, const uint8_t *proof, size_t len, uint64_t a, uint64_t b, uint64_t x,
+                              unsigned log_n, const p3hip_fri_params_t *params);
+
 /* ---- batches of independent proofs (BASELINE configs[3]; SURVEY.md §8e: instance i is self-contained) ------
  * A pool of n_provers provers, each on its own host thread (thread-local context, as the reference's runtime,
  * backend_vulkan.rs:100-102) and its own stream, so the transcript round trips of one proof hide behind the

@@ -352,6 +352,10 @@ extern "C" {
 
 int p3hip_fib_prover_create(unsigned log_n, const p3hip_fri_params_t* params, void* stream, int own_stream,
                             p3hip_fib_prover_t** out) {
+    return p3hip_fib_prover_create_hash(HASH_POSEIDON2, log_n, params, stream, own_stream, out);
+}
+int p3hip_fib_prover_create_hash(int hash, unsigned log_n, const p3hip_fri_params_t* params, void* stream, int own_stream,
+                                 p3hip_fib_prover_t** out) {
     return guarded([&]() -> int {
         if (!params || !out) return fail(ERR_BAD_ARG, "fib_prover_create: null argument");
         Context* cx;
@@ -365,7 +369,7 @@ int p3hip_fib_prover_create(unsigned log_n, const p3hip_fri_params_t* params, vo
         }
         std::unique_ptr<p3hip_fib_prover> p(new p3hip_fib_prover());
         FriParams fp{params->log_blowup, params->log_final_poly_len, params->num_queries, params->proof_of_work_bits};
-        rc = p->prover.init(log_n, fp, st, own);
+        rc = p->prover.init(log_n, fp, st, own, hash);
         if (rc) return rc;
         *out = p.release();
         return OK;
@@ -398,11 +402,15 @@ void p3hip_fib_prover_destroy(p3hip_fib_prover_t* prover) { delete prover; }
 
 int p3hip_verify_fib_air(const uint8_t* proof, size_t len, uint64_t a, uint64_t b, uint64_t x, unsigned log_n,
                          const p3hip_fri_params_t* params) {
+    return p3hip_verify_fib_air_hash(HASH_POSEIDON2, proof, len, a, b, x, log_n, params);
+}
+int p3hip_verify_fib_air_hash(int hash, const uint8_t* proof, size_t len, uint64_t a, uint64_t b, uint64_t x, unsigned log_n,
+                              const p3hip_fri_params_t* params) {
     return guarded([&]() -> int {
         if (!proof || !params) return fail(ERR_BAD_ARG, "verify_fib_air: null argument");
         FriParams fp{params->log_blowup, params->log_final_poly_len, params->num_queries, params->proof_of_work_bits};
         std::string why;
-        int rc = verify_fib_air(proof, len, a, b, x, log_n, fp, &why);
+        int rc = verify_fib_air(proof, len, a, b, x, log_n, fp, &why, hash);
         if (rc != 0) set_error("fib_air verification failed: " + why);
         return rc;
     });

@@ -23,7 +23,7 @@ class FibProver {
     FibProver();
     ~FibProver();
     FibProver(const FibProver&) = delete;
-    int init(uint32_t log_n, const FriParams& fp, hipStream_t stream, bool own_stream);
+    int init(uint32_t log_n, const FriParams& fp, hipStream_t stream, bool own_stream, int hash = 0);  // mmcs.h HashKind
     // proves the FibonacciAir instance with first row (a, b); public values [a, b, last right value]
     int prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof);
     const StageTimes& times() const;
@@ -36,6 +36,6 @@ class FibProver {
 
 // verifier.hip: p3_uni_stark::verify for FibonacciAir on the host (0 = accept, else the failed check's code)
 int verify_fib_air(const uint8_t* proof, size_t len, uint64_t a_pub, uint64_t b_pub, uint64_t x_pub, uint32_t log_n,
-                   const FriParams& fp, std::string* why);
+                   const FriParams& fp, std::string* why, int hash = 0);
 
 }  // namespace p3

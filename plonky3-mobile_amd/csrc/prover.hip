@@ -2,7 +2,9 @@
 //
 // Stands in for the call chain the reference drives at native/src/fib_air.rs:60-70
 //   p3_uni_stark::prove -> TwoAdicFriPcs::{commit, open} -> p3_fri::prove (commit phase, grind, queries)
-// instantiated as north_star asks (BabyBear, Poseidon2 MMCS + DuplexChallenger<_, Perm16, 16, 8>, non-hiding).
+// instantiated as north_star asks (BabyBear, Poseidon2 MMCS + DuplexChallenger<_, Perm16, 16, 8>, non-hiding), or —
+// hash = HASH_KECCAK — with the reference's own hashes (fib_air.rs:28-53: Keccak MMCS + SerializingChallenger32 over
+// a Keccak-256 HashChallenger; still non-hiding).
 // Device: trace (fib_air.hip), coset LDEs (ntt.hip), Merkle trees (mmcs.hip) and the kernels below:
 //   selectors table, quotient values, inverse denominators 1/(z - x), barycentric openings,
 //   reduced (DEEP) openings, FRI folds, proof-of-work search, batched query gathers.
@@ -14,7 +16,9 @@
 #include <cstring>
 
 #include "bb31.cuh"
+#include "challenger.h"
 #include "common.h"
+#include "keccak.cuh"
 #include "mmcs.h"
 #include "poseidon2.cuh"
 #include "prover.h"
@@ -22,35 +26,6 @@
 namespace p3 {
 
 using bb::Ext;
-
-// ------------------------------------------------------------------------------------------------
-// host: DuplexChallenger<BabyBear, Poseidon2-16, WIDTH 16, RATE 8>
-// ------------------------------------------------------------------------------------------------
-struct Challenger {
-    uint32_t state[16] = {0}, in[8] = {0}, out[8] = {0};
-    int n_in = 0, n_out = 0;
-    void duplex() {
-        for (int i = 0; i < n_in; i++) state[i] = in[i];
-        n_in = 0;
-        p2::permute(state);
-        memcpy(out, state, 32);
-        n_out = 8;
-    }
-    void observe(uint32_t v) {
-        n_out = 0;
-        in[n_in++] = v;
-        if (n_in == 8) duplex();
-    }
-    void observe_n(const uint32_t* v, size_t n) { for (size_t i = 0; i < n; i++) observe(v[i]); }
-    void observe_ext(const Ext& e) { observe_n(e.c, 4); }
-    uint32_t sample() {
-        if (n_in || !n_out) duplex();
-        return out[--n_out];
-    }
-    Ext sample_ext() { Ext r; for (int i = 0; i < 4; i++) r.c[i] = sample(); return r; }
-    size_t sample_bits(unsigned bits) { return (size_t)bb::from_monty(sample()) & (((size_t)1 << bits) - 1); }
-    bool check_witness(unsigned bits, uint32_t w) { observe(w); return sample_bits(bits) == 0; }
-};
 
 // ------------------------------------------------------------------------------------------------
 // device kernels
@@ -266,6 +241,49 @@ __global__ void __launch_bounds__(256) grind_kernel(const uint32_t* state16, uin
     if ((bb::from_monty(s[7]) & mask) == 0) atomicMin(result, w);
 }
 
+// The same search for the Keccak-256 HashChallenger: candidate w is observed as the 4 little-endian bytes of its
+// Montgomery word after the pending input bytes; the host has absorbed the complete 136-byte blocks already and
+// hands over the state plus up to two template blocks (pending tail bytes, zeroed witness bytes, 0x01 / 0x80
+// padding).  sample_bits pops digest bytes from the back, four per try, masks to 31 bits and retries while >= P.
+struct KeccakGrindArgs {
+    uint64_t state[25];
+    uint64_t block[2][17];
+    uint32_t n_blocks, wpos;  // witness byte offset within the template (may straddle lanes and blocks)
+    uint32_t mask, base;
+};
+__global__ void __launch_bounds__(256) grind_keccak_kernel(KeccakGrindArgs a, uint32_t* result) {
+    uint32_t w = a.base + blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= bb::P) return;
+    const uint32_t wm = bb::to_monty(w);
+    uint64_t st[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) st[i] = a.state[i];
+    for (uint32_t blk = 0; blk < a.n_blocks; blk++) {
+#pragma unroll
+        for (int i = 0; i < 17; i++) {
+            uint64_t lane = a.block[blk][i];
+            // witness bytes that fall into this lane: byte b of the word sits at template offset wpos + b
+            const int32_t rel = (int32_t)(a.wpos) - (int32_t)(blk * 136 + i * 8);  // offset of byte 0 within the lane
+            if (rel > -4 && rel < 8) {
+                const uint64_t v = (uint64_t)wm;
+                lane ^= rel >= 0 ? (v << (8 * rel)) : (v >> (8 * -rel));
+            }
+            st[i] ^= lane;
+        }
+        kk::permute(st);
+    }
+    // digest bytes d[0..31] = lanes 0..3 little endian; pops come from d[31] downwards
+    bool ok = false;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const uint64_t lane = st[3 - t / 2];
+        const uint32_t hi_or_lo = (t & 1) ? (uint32_t)lane : (uint32_t)(lane >> 32);  // bytes 4k+3 .. 4k, k = 7 - t
+        const uint32_t v = __builtin_bswap32(hi_or_lo) & 0x7fffffffu;                // first pop = low byte
+        if (v < bb::P) { ok = (v & a.mask) == 0; break; }
+    }
+    if (ok) atomicMin(result, w);
+}
+
 // Batched Mmcs::open_batch for the query phase: block (q, t) copies tree t's opened row and sibling path
 // for query q into its fixed slot of the staging buffer.
 struct QTree {
@@ -303,6 +321,7 @@ static void put_words(std::vector<uint8_t>& b, const uint32_t* w, size_t n) {
 }
 
 struct FibProver::Impl {
+    int hash = HASH_POSEIDON2;
     uint32_t log_n = 0, log_big = 0;
     FriParams fp{};
     hipStream_t stream = nullptr;
@@ -338,7 +357,9 @@ struct FibProver::Impl {
 FibProver::FibProver() : im(new Impl()) {}
 FibProver::~FibProver() { delete im; }
 
-int FibProver::init(uint32_t log_n, const FriParams& fp, hipStream_t stream, bool own_stream) {
+int FibProver::init(uint32_t log_n, const FriParams& fp, hipStream_t stream, bool own_stream, int hash) {
+    if (hash != HASH_POSEIDON2 && hash != HASH_KECCAK) return fail(ERR_BAD_ARG, "fib prover: unknown hash configuration");
+    im->hash = hash;
     Impl& s = *im;
     if (log_n < 1) return fail(ERR_BAD_ARG, "fib prover: log_n must be >= 1");
     if (log_n + fp.log_blowup > bb::TWO_ADICITY || log_n + fp.log_blowup > 31)
@@ -445,7 +466,7 @@ int FibProver::prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof) {
     const uint32_t* mp[1] = {s.lde_t};
     size_t hh[1] = {big}, ww[1] = {2};
     Tree* tp = nullptr;
-    if ((rc = mmcs_commit(st, mp, hh, ww, 1, &tp, s.layers_t, s.dev_roots))) return rc;
+    if ((rc = mmcs_commit(st, mp, hh, ww, 1, &tp, s.layers_t, s.dev_roots, s.hash))) return rc;
     std::unique_ptr<Tree> tree_t(tp);
     // public values: first row and last right value
     uint32_t* hp = s.host_pinned;
@@ -456,10 +477,10 @@ int FibProver::prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof) {
     uint32_t root_t[8], pis[3] = {hp[8], hp[9], hp[10]};
     memcpy(root_t, s.host_roots, 32);
     double t1 = now_ms();
-    Challenger ch;
+    Challenger ch(s.hash);
     ch.observe(bb::to_monty(log_n));
     ch.observe(bb::to_monty(log_n));
-    ch.observe_n(root_t, 8);
+    ch.observe_digest(root_t);
     ch.observe_n(pis, 3);
     Ext alpha = ch.sample_ext();
 
@@ -482,14 +503,14 @@ int FibProver::prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof) {
     }
     if ((rc = ntt_coset_lde(cx, st, s.qflat, s.lde_q, n, 4, s.fp.log_blowup, bb::ONE, true))) return rc;
     mp[0] = s.lde_q; ww[0] = 4;
-    if ((rc = mmcs_commit(st, mp, hh, ww, 1, &tp, s.layers_q, s.dev_roots + 8))) return rc;
+    if ((rc = mmcs_commit(st, mp, hh, ww, 1, &tp, s.layers_q, s.dev_roots + 8, s.hash))) return rc;
     std::unique_ptr<Tree> tree_q(tp);
     uint32_t root_q[8];
     if (!tree_q->root_copied) P3_HIP(hipMemcpyAsync(s.host_roots + 8, tree_q->layers + tree_q->layer_off.back(), 32, hipMemcpyDeviceToHost, st));
     P3_HIP(hipStreamSynchronize(st));
     memcpy(root_q, s.host_roots + 8, 32);
     double t2 = now_ms();
-    ch.observe_n(root_q, 8);
+    ch.observe_digest(root_q);
     Ext zeta = ch.sample_ext();
     Ext zeta_next = bb::scale(zeta, g_n);
 
@@ -549,12 +570,12 @@ int FibProver::prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof) {
         mp[0] = s.fri_vec + s.fri_vec_off[r];
         hh[0] = half; ww[0] = 8;  // ExtensionMmcs: rows of two ext elements, flattened
         uint32_t slot = 16 + 8 * (r % 32);
-        if ((rc = mmcs_commit(st, mp, hh, ww, 1, &tp, s.fri_layers + s.fri_layer_off[r], s.dev_roots + slot))) return rc;
+        if ((rc = mmcs_commit(st, mp, hh, ww, 1, &tp, s.fri_layers + s.fri_layer_off[r], s.dev_roots + slot, s.hash))) return rc;
         ftrees.emplace_back(tp);
         if (!tp->root_copied) P3_HIP(hipMemcpyAsync(s.host_roots + slot, tp->layers + tp->layer_off.back(), 32, hipMemcpyDeviceToHost, st));
         P3_HIP(hipStreamSynchronize(st));
         memcpy(&froots[(size_t)r * 8], s.host_roots + slot, 32);
-        ch.observe_n(&froots[(size_t)r * 8], 8);
+        ch.observe_digest(&froots[(size_t)r * 8]);
         Ext beta = ch.sample_ext();
         TwoLevelTable inv_roots;
         uint32_t log_half = log_big - 1 - r;
@@ -591,20 +612,44 @@ int FibProver::prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof) {
     // ---- proof of work ----
     uint32_t witness = 0;
     {
-        Challenger c2 = ch;  // state with the pending inputs applied, witness slot = n_in
-        uint32_t pre[16];
-        memcpy(pre, c2.state, 64);
-        for (int i = 0; i < c2.n_in; i++) pre[i] = c2.in[i];
-        uint32_t pos = (uint32_t)c2.n_in;
-        memcpy(hp, pre, 64);
-        hp[16] = 0xffffffffu;
-        P3_HIP(hipMemcpyAsync(s.small, hp, 68, hipMemcpyHostToDevice, st));
         uint32_t mask = (1u << s.fp.proof_of_work_bits) - 1u;
+        KeccakGrindArgs ka{};
+        uint32_t pos = 0;
+        if (s.hash == HASH_KECCAK) {
+            // pending input = chaining digest + the bytes observed since; complete blocks are absorbed here
+            size_t done = keccak256_absorb_full(ka.state, ch.ibuf.data(), ch.ibuf.size());
+            size_t tail = ch.ibuf.size() - done;
+            uint8_t tmpl[272] = {0};
+            memcpy(tmpl, ch.ibuf.data() + done, tail);
+            size_t end = tail + 4;                       // message end within the template
+            ka.n_blocks = end < 136 ? 1 : 2;
+            tmpl[end] ^= 0x01;
+            tmpl[(size_t)ka.n_blocks * 136 - 1] ^= 0x80;
+            memcpy(ka.block, tmpl, 272);
+            ka.wpos = (uint32_t)tail;
+            ka.mask = mask;
+            hp[16] = 0xffffffffu;
+            P3_HIP(hipMemcpyAsync(s.small + 16, hp + 16, 4, hipMemcpyHostToDevice, st));
+        } else {
+            Challenger c2 = ch;  // state with the pending inputs applied, witness slot = n_in
+            uint32_t pre[16];
+            memcpy(pre, c2.state, 64);
+            for (int i = 0; i < c2.n_in; i++) pre[i] = c2.in[i];
+            pos = (uint32_t)c2.n_in;
+            memcpy(hp, pre, 64);
+            hp[16] = 0xffffffffu;
+            P3_HIP(hipMemcpyAsync(s.small, hp, 68, hipMemcpyHostToDevice, st));
+        }
         // expected 2^bits candidates: first launch covers 2x that (P[miss] = e^-2), each later one 4x the previous
         uint32_t batch = 1u << std::min<uint32_t>(std::max<uint32_t>(s.fp.proof_of_work_bits + 1, 10), 24);
         uint32_t found = 0xffffffffu;
         for (uint64_t base = 0; base < bb::P && found == 0xffffffffu; base += batch, batch = std::min<uint32_t>(batch * 4, 1u << 24)) {
-            hipLaunchKernelGGL(grind_kernel, dim3(batch / 256), dim3(256), 0, st, s.small, pos, mask, (uint32_t)base, s.small + 16);
+            if (s.hash == HASH_KECCAK) {
+                ka.base = (uint32_t)base;
+                hipLaunchKernelGGL(grind_keccak_kernel, dim3(batch / 256), dim3(256), 0, st, ka, s.small + 16);
+            } else {
+                hipLaunchKernelGGL(grind_kernel, dim3(batch / 256), dim3(256), 0, st, s.small, pos, mask, (uint32_t)base, s.small + 16);
+            }
             P3_HIP(hipGetLastError());
             P3_HIP(hipMemcpyAsync(hp + 32, s.small + 16, 4, hipMemcpyDeviceToHost, st));
             P3_HIP(hipStreamSynchronize(st));

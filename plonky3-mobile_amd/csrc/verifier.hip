@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "bb31.cuh"
+#include "challenger.h"
 #include "common.h"
 #include "poseidon2.cuh"
 #include "prover.h"
@@ -17,24 +18,14 @@ using bb::Ext;
 
 namespace {
 
-struct Chal {  // DuplexChallenger<BabyBear, Poseidon2-16, 16, 8>
-    uint32_t state[16] = {0}, in[8] = {0}, out[8] = {0};
-    int n_in = 0, n_out = 0;
-    void duplex() { for (int i = 0; i < n_in; i++) state[i] = in[i]; n_in = 0; p2::permute(state); memcpy(out, state, 32); n_out = 8; }
-    void observe(uint32_t v) { n_out = 0; in[n_in++] = v; if (n_in == 8) duplex(); }
-    void observe_n(const uint32_t* v, size_t n) { for (size_t i = 0; i < n; i++) observe(v[i]); }
-    void observe_ext(const Ext& e) { observe_n(e.c, 4); }
-    uint32_t sample() { if (n_in || !n_out) duplex(); return out[--n_out]; }
-    Ext sample_ext() { Ext r; for (int i = 0; i < 4; i++) r.c[i] = sample(); return r; }
-    size_t sample_bits(unsigned bits) { return (size_t)bb::from_monty(sample()) & (((size_t)1 << bits) - 1); }
-};
-
 struct Reader {
     const uint8_t* p; size_t len, pos = 0; bool bad = false;
     uint32_t u32() { uint32_t v = 0; if (pos + 4 > len) { bad = true; return 0; } memcpy(&v, p + pos, 4); pos += 4; return v; }
     uint32_t felt() { uint32_t v = u32(); if (v >= bb::P) bad = true; return v; }
     void felts(uint32_t* w, size_t n) { for (size_t i = 0; i < n; i++) w[i] = felt(); }
     Ext ext() { Ext e; felts(e.c, 4); return e; }
+    // n digests: 8 field elements each (Poseidon2) or raw [u64; 4] bytes (Keccak)
+    void digests(int hash, uint32_t* w, size_t n) { if (hash == HASH_POSEIDON2) felts(w, 8 * n); else for (size_t i = 0; i < 8 * n; i++) w[i] = u32(); }
 };
 
 void hash_row(const uint32_t* items, size_t n, uint32_t out[8]) {  // PaddingFreeSponge<_, 16, 8, 8>
@@ -46,12 +37,13 @@ void compress(const uint32_t* l, const uint32_t* r, uint32_t out[8]) {  // Trunc
     uint32_t st[16]; memcpy(st, l, 32); memcpy(st + 8, r, 32); p2::permute(st); memcpy(out, st, 32);
 }
 // MerkleTreeMmcs::verify_batch for a single matrix
-bool verify_opening(const uint32_t root[8], size_t index, const uint32_t* row, size_t width, const uint32_t* path, unsigned depth) {
+bool verify_opening(int hash, const uint32_t root[8], size_t index, const uint32_t* row, size_t width, const uint32_t* path, unsigned depth) {
     uint32_t cur[8], nxt[8];
-    hash_row(row, width, cur);
+    auto cmp = hash == HASH_KECCAK ? keccak_compress_host : compress;
+    if (hash == HASH_KECCAK) keccak_hash_row_host(row, width, cur); else hash_row(row, width, cur);
     for (unsigned l = 0; l < depth; l++) {
         const uint32_t* sib = path + 8 * (size_t)l;
-        if ((index >> l) & 1) compress(sib, cur, nxt); else compress(cur, sib, nxt);
+        if ((index >> l) & 1) cmp(sib, cur, nxt); else cmp(cur, sib, nxt);
         memcpy(cur, nxt, 32);
     }
     return memcmp(cur, root, 32) == 0;
@@ -62,7 +54,8 @@ size_t rev_bits_host(size_t x, unsigned bits) { size_t y = 0; for (unsigned i = 
 
 // 0 = accept; otherwise a positive code naming the failed check (same numbering as the error strings below).
 int verify_fib_air(const uint8_t* proof, size_t len, uint64_t a_pub, uint64_t b_pub, uint64_t x_pub, uint32_t log_n,
-                   const FriParams& fp, std::string* why) {
+                   const FriParams& fp, std::string* why, int hash) {
+    if (hash != HASH_POSEIDON2 && hash != HASH_KECCAK) { if (why) *why = "unknown hash configuration"; return -1; }
     auto reject = [&](int code, const char* msg) { if (why) *why = msg; return code; };
     Reader rd{proof, len};
     const uint32_t log_big = log_n + fp.log_blowup;
@@ -71,7 +64,7 @@ int verify_fib_air(const uint8_t* proof, size_t len, uint64_t a_pub, uint64_t b_
     if (rd.u32() != 0x42463350u || rd.u32() != 1) return reject(1, "bad header");
     if (rd.u32() != log_n) return reject(2, "degree_bits mismatch");
     uint32_t root_t[8], root_q[8];
-    rd.felts(root_t, 8); rd.felts(root_q, 8);
+    rd.digests(hash, root_t, 1); rd.digests(hash, root_q, 1);
     Ext t_loc[2], t_nxt[2], q_z[4];
     if (rd.u32() != 2) return reject(3, "opened values shape");
     for (auto& e : t_loc) e = rd.ext();
@@ -81,11 +74,11 @@ int verify_fib_air(const uint8_t* proof, size_t len, uint64_t a_pub, uint64_t b_
     for (auto& e : q_z) e = rd.ext();
     if (rd.bad) return reject(4, "truncated proof");
     uint32_t pis[3] = {bb::to_monty((uint32_t)(a_pub % bb::P)), bb::to_monty((uint32_t)(b_pub % bb::P)), bb::to_monty((uint32_t)(x_pub % bb::P))};
-    Chal ch;
+    Challenger ch(hash);
     ch.observe(bb::to_monty(log_n)); ch.observe(bb::to_monty(log_n));
-    ch.observe_n(root_t, 8); ch.observe_n(pis, 3);
+    ch.observe_digest(root_t); ch.observe_n(pis, 3);
     Ext alpha = ch.sample_ext();
-    ch.observe_n(root_q, 8);
+    ch.observe_digest(root_q);
     Ext zeta = ch.sample_ext();
     const uint32_t g_n = bb::two_adic_generator(log_n);
     Ext zeta_next = bb::scale(zeta, g_n);
@@ -114,8 +107,8 @@ int verify_fib_air(const uint8_t* proof, size_t len, uint64_t a_pub, uint64_t b_
     if (rd.bad || n_rounds != log_big - fp.log_blowup - fp.log_final_poly_len) return reject(5, "commit phase length");
     std::vector<uint32_t> froots((size_t)n_rounds * 8);
     std::vector<Ext> betas(n_rounds);
-    rd.felts(froots.data(), froots.size());
-    for (uint32_t r = 0; r < n_rounds; r++) { ch.observe_n(&froots[(size_t)r * 8], 8); betas[r] = ch.sample_ext(); }
+    rd.digests(hash, froots.data(), froots.size() / 8);
+    for (uint32_t r = 0; r < n_rounds; r++) { ch.observe_digest(&froots[(size_t)r * 8]); betas[r] = ch.sample_ext(); }
     if (rd.u32() != fp.num_queries) return reject(6, "query count");
     const size_t qstart = rd.pos;
     for (uint32_t q = 0; q < fp.num_queries && !rd.bad; q++) {  // skip to the final polynomial
@@ -140,12 +133,12 @@ int verify_fib_air(const uint8_t* proof, size_t len, uint64_t a_pub, uint64_t b_
         if (rd.u32() != 2) return reject(12, "query shape");  // one BatchOpening per commitment round
         if (rd.u32() != 1 || rd.u32() != 2) return reject(12, "query shape");
         rd.felts(trow, 2);
-        if (rd.u32() != log_big) return reject(12, "query shape"); rd.felts(path.data(), 8 * (size_t)log_big);
-        if (!verify_opening(root_t, index, trow, 2, path.data(), log_big)) return reject(13, "trace opening");
+        if (rd.u32() != log_big) return reject(12, "query shape"); rd.digests(hash, path.data(), log_big);
+        if (!verify_opening(hash, root_t, index, trow, 2, path.data(), log_big)) return reject(13, "trace opening");
         if (rd.u32() != 1 || rd.u32() != 4) return reject(12, "query shape");
         rd.felts(qrow, 4);
-        if (rd.u32() != log_big) return reject(12, "query shape"); rd.felts(path.data(), 8 * (size_t)log_big);
-        if (!verify_opening(root_q, index, qrow, 4, path.data(), log_big)) return reject(13, "quotient opening");
+        if (rd.u32() != log_big) return reject(12, "query shape"); rd.digests(hash, path.data(), log_big);
+        if (!verify_opening(hash, root_q, index, qrow, 4, path.data(), log_big)) return reject(13, "quotient opening");
         const uint32_t xi = bb::mul(gen, bb::pow(bb::two_adic_generator(log_big), rev_bits_host(index, log_big)));
         Ext d0 = bb::inv(bb::sub(zeta, bb::ext_from_base(xi))), d1 = bb::inv(bb::sub(zeta_next, bb::ext_from_base(xi)));
         Ext ro = bb::ext_zero();
@@ -160,13 +153,13 @@ int verify_fib_air(const uint8_t* proof, size_t len, uint64_t a_pub, uint64_t b_
             const uint32_t lfh = log_big - 1 - r;
             Ext sib = rd.ext();
             if (rd.u32() != lfh) return reject(12, "query shape");
-            rd.felts(path.data(), 8 * (size_t)lfh);
+            rd.digests(hash, path.data(), lfh);
             Ext ev[2];
             ev[idx & 1] = folded; ev[(idx & 1) ^ 1] = sib;
             const size_t pair = idx >> 1;
             uint32_t row8[8];
             memcpy(row8, ev[0].c, 16); memcpy(row8 + 4, ev[1].c, 16);
-            if (!verify_opening(&froots[(size_t)r * 8], pair, row8, 8, path.data(), lfh)) return reject(14, "FRI layer opening");
+            if (!verify_opening(hash, &froots[(size_t)r * 8], pair, row8, 8, path.data(), lfh)) return reject(14, "FRI layer opening");
             const uint32_t s = bb::pow(bb::two_adic_generator(lfh + 1), rev_bits_host(pair, lfh));
             Ext num = bb::mul(bb::sub(betas[r], bb::ext_from_base(s)), bb::sub(ev[1], ev[0]));
             folded = bb::add(ev[0], bb::scale(num, bb::inv(bb::sub(bb::neg(s), s))));

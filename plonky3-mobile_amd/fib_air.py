@@ -31,17 +31,27 @@ class FriParameters:
         return arr
 
 
+def _hash_kind(hash):
+    kinds = {"poseidon2": 0, "keccak": 1}
+    if hash not in kinds:
+        raise ValueError("unknown hash configuration %r" % (hash,))
+    return kinds[hash]
+
+
 class FibAirProver:
     """prove(&config, &FibonacciAir{}, generate_trace_rows(a, b, 2^log_n), &[a, b, x]) (fib_air.rs:61-70)
     on the hip backend.  One instance = one HBM arena + one stream; use one per host thread."""
 
-    def __init__(self, log_n, log_blowup=1, params=None, own_stream=True):
+    def __init__(self, log_n, log_blowup=1, params=None, own_stream=True, hash="poseidon2"):
+        """hash="keccak": the reference's own hash configuration (fib_air.rs:28-53: Keccak MMCS +
+        SerializingChallenger32 over a Keccak-256 HashChallenger), non-hiding."""
         self.params = params or FriParameters(log_blowup=log_blowup)
         self.log_n = log_n
+        self.hash = hash
         self._h = C.c_void_p()
         stream = None if own_stream else _stream_ptr()
-        _lib.check(_lib.lib().p3hip_fib_prover_create(log_n, C.cast(self.params._c(), C.c_void_p), stream,
-                                                      1 if own_stream else 0, C.byref(self._h)))
+        _lib.check(_lib.lib().p3hip_fib_prover_create_hash(_hash_kind(hash), log_n, C.cast(self.params._c(), C.c_void_p),
+                                                           stream, 1 if own_stream else 0, C.byref(self._h)))
 
     def prove(self, a, b):
         """Returns the proof bytes (wire format: DESIGN.md)."""
@@ -186,26 +196,27 @@ def fib_public_x(a, b, n):
     return r
 
 
-def verify_fib_air(proof, a, b, x, log_n, params=None):
+def verify_fib_air(proof, a, b, x, log_n, params=None, hash="poseidon2"):
     """verify(&config, &FibonacciAir{}, &proof, &[a, b, x]) (fib_air.rs:71-72), host side.  Raises
     P3HipError("fib_air verification failed: <check>") on rejection, like the reference's map_err."""
     params = params or FriParameters()
     buf = (C.c_uint8 * len(proof)).from_buffer_copy(proof)
-    _lib.check(_lib.lib().p3hip_verify_fib_air(buf, len(proof), a, b, x, log_n, C.cast(params._c(), C.c_void_p)))
+    _lib.check(_lib.lib().p3hip_verify_fib_air_hash(_hash_kind(hash), buf, len(proof), a, b, x, log_n,
+                                                    C.cast(params._c(), C.c_void_p)))
 
 
-def run_fib_air(log_n=3, a=0, b=1, params=None):
-    """run_fib_air_zk (fib_air.rs:27-75) on the hip backend with the Poseidon2 configuration: prove, verify,
-    report.  Default n = 8, x = 21 as in the reference (fib_air.rs:56-57)."""
+def run_fib_air(log_n=3, a=0, b=1, params=None, hash="poseidon2"):
+    """run_fib_air_zk (fib_air.rs:27-75) on the hip backend: prove, verify, report.  Default n = 8, x = 21 as in the
+    reference (fib_air.rs:56-57).  hash="keccak" selects the reference's own hashes (non-hiding)."""
     params = params or FriParameters()
     n = 1 << log_n
     x = fib_public_x(a, b, n)
-    prover = FibAirProver(log_n, params=params)
+    prover = FibAirProver(log_n, params=params, hash=hash)
     try:
         proof = prover.prove(a, b)
     finally:
         prover.close()
-    verify_fib_air(proof, a, b, x, log_n, params)
+    verify_fib_air(proof, a, b, x, log_n, params, hash=hash)
     return "fib_air ok (n=%d, x=%d)" % (n, x)
 
 

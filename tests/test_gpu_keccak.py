@@ -69,3 +69,37 @@ def test_keccak_tree_of_the_fib_air_lde(p3, oracle):
     assert oracle.mmcs_verify_batch(root, [(2 * n, 2)], 12345, rows[0], path, oracle.HASH_KECCAK)
     with pytest.raises(ValueError):
         p3.MerkleTreeMmcs(hash="sha256")
+
+
+@pytest.mark.parametrize("log_n,t", [(1, (1, 0, 8, 4)), (3, (1, 0, 10, 4)), (8, (1, 0, 30, 8)), (10, (2, 1, 12, 10)),
+                                     (12, (1, 0, 100, 16)), (14, (1, 3, 20, 12)), (11, (1, 4, 9, 7))])
+def test_keccak_config_proof_bytes_equal_the_oracle(p3, oracle, log_n, t):
+    """fib_air proved on the GPU under the reference's own hashes: proof bytes identical to the oracle's, accepted by
+    both verifiers.  (1, 4, ..) and (1, 3, ..) make the pending transcript bytes at grind time cross a 136-byte
+    block boundary: 32 chaining + 16 * 2^lfp final-polynomial bytes.)"""
+    K = oracle.HASH_KECCAK
+    gfp, ofp = p3.FriParameters(*t), oracle.FriParams(*t)
+    prover = p3.FibAirProver(log_n, params=gfp, hash="keccak")
+    try:
+        for a in (0, 7):
+            proof = prover.prove(a, a + 1)
+            assert proof == oracle.prove_fib_air(a, a + 1, log_n, ofp, hash=K)
+            x = oracle.fib_public_x(a, a + 1, 1 << log_n)
+            assert oracle.verify_fib_air(proof, a, a + 1, x, log_n, ofp, hash=K) == 0
+            p3.verify_fib_air(proof, a, a + 1, x, log_n, gfp, hash="keccak")
+    finally:
+        prover.close()
+
+
+def test_keccak_config_headline_size(p3, oracle):
+    """2^20 rows, benchmark FRI parameters: the oracle's verifier accepts the GPU proof (the oracle prover would need
+    ~20 s here; equality of bytes is covered at the smaller sizes above)."""
+    prover = p3.FibAirProver(20, hash="keccak")
+    try:
+        proof = prover.prove(0, 1)
+        assert prover.prove(0, 1) == proof
+    finally:
+        prover.close()
+    x = oracle.fib_public_x(0, 1, 1 << 20)
+    assert oracle.verify_fib_air(proof, 0, 1, x, 20, oracle.FriParams(), hash=oracle.HASH_KECCAK) == 0
+    assert p3.run_fib_air(hash="keccak") == "fib_air ok (n=8, x=21)"

@@ -73,3 +73,28 @@ def test_product_verifier_accepts_oracle_proofs_and_rejects_tampering(p3, oracle
             with pytest.raises(p3.P3HipError):
                 p3.verify_fib_air(bad.tobytes(), 0, 1, x, log_n, gfp)
             assert oracle.verify_fib_air(bad.tobytes(), 0, 1, x, log_n, ofp) != 0
+
+
+def test_product_verifier_keccak_configuration(p3, oracle):
+    """The host verifier under the reference's own hashes (Keccak MMCS + SerializingChallenger32 / Keccak-256
+    HashChallenger) against the oracle's prover for the same configuration; the two were written separately."""
+    import numpy as np
+    K = oracle.HASH_KECCAK
+    for log_n, t in [(3, (1, 0, 10, 4)), (6, (2, 2, 6, 5)), (9, (1, 1, 20, 8))]:
+        ofp, gfp = oracle.FriParams(*t), p3.FriParameters(*t)
+        proof = oracle.prove_fib_air(3, 4, log_n, ofp, hash=K)
+        x = p3.fib_public_x(3, 4, 1 << log_n)
+        p3.verify_fib_air(proof, 3, 4, x, log_n, gfp, hash="keccak")  # accepts
+        with pytest.raises(p3.P3HipError):
+            p3.verify_fib_air(proof, 3, 4, x, log_n, gfp)              # Poseidon2 verifier, Keccak proof
+        with pytest.raises(p3.P3HipError, match="OodEvaluationMismatch"):
+            p3.verify_fib_air(proof, 3, 4, x + 1, log_n, gfp, hash="keccak")
+        words = np.frombuffer(proof, dtype=np.uint32)
+        rng = np.random.default_rng(log_n)
+        for pos in rng.choice(len(words), size=25, replace=False):
+            bad = words.copy()
+            bad[pos] = (int(bad[pos]) + 1) % 0x78000001
+            with pytest.raises(p3.P3HipError):
+                p3.verify_fib_air(bad.tobytes(), 3, 4, x, log_n, gfp, hash="keccak")
+    with pytest.raises(ValueError):
+        p3.verify_fib_air(proof, 3, 4, x, log_n, gfp, hash="sha2")

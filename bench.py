@@ -24,7 +24,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 
 
-def cpu_baseline(log_height, log_blowup, job):
+def cpu_baseline(log_height, log_blowup, job, hash_kind=0):
     """The reference CPU prover (Rust + Plonky3) cannot be built here, so the baseline is the
     repo's C restatement (oracle/, kind "port"), single-threaded like the reference build
     (native/Cargo.toml:32-43 enables no `parallel` feature), timed on this host on the SAME instance.
@@ -35,7 +35,7 @@ def cpu_baseline(log_height, log_blowup, job):
                                                          "proof_of_work_bits")])
     o.set_threads(1)
     t0 = time.perf_counter()
-    proof = o.prove_fib_air(0, 1, log_height, fp)
+    proof = o.prove_fib_air(0, 1, log_height, fp, hash=hash_kind)
     dt = time.perf_counter() - t0
     # the same port with its OpenMP loops (Merkle layers, quotient, openings, folds) on every host core
     # the GPU box gives one GPU's job a share of about 16 host cores whatever nproc says
@@ -46,11 +46,11 @@ def cpu_baseline(log_height, log_blowup, job):
     cores = max(1, min(o.max_threads(), avail, int(os.environ.get("P3HIP_BENCH_CPU_THREADS", "16"))))
     o.set_threads(cores)
     t1 = time.perf_counter()
-    proof_mt = o.prove_fib_air(0, 1, log_height, fp)
+    proof_mt = o.prove_fib_air(0, 1, log_height, fp, hash=hash_kind)
     dt_mt = time.perf_counter() - t1
     o.set_threads(1)
     gpu = job.prove_one(0, 1)
-    ok = o.verify_fib_air(gpu, 0, 1, o.fib_public_x(0, 1, 1 << log_height), log_height, fp) == 0
+    ok = o.verify_fib_air(gpu, 0, 1, o.fib_public_x(0, 1, 1 << log_height), log_height, fp, hash=hash_kind) == 0
     return {"value": 1.0 / dt, "unit": "proofs/s", "cores": 1, "kind": "port",
             "sample": "1 full fib_air proof, instance (a,b)=(0,1), 2^%d rows, same FRI parameters" % log_height,
             "seconds": dt, "proof_bytes_equal_to_gpu": bool(gpu == proof), "oracle_verifier_accepts_gpu_proof": bool(ok),
@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="independent proofs per rank per step")
     ap.add_argument("--threads", type=int, default=8, help="concurrent provers (host threads/streams) per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hash", choices=["poseidon2", "keccak"], default="poseidon2",
+                    help="poseidon2 = BASELINE.json's configuration (default); keccak = the hashes the reference itself wires")
     args = ap.parse_args()
 
     import torch
@@ -99,7 +101,7 @@ def main():
     n = 1 << args.log_height
     from plonky3_mobile_amd import bench_support as bs
     job = bs.FibAirJob(p3, args.log_height, args.log_blowup, args.batch, first_instance=rank * args.batch,
-                       threads=args.threads)
+                       threads=args.threads, hash=args.hash)
 
     def barrier():
         torch.cuda.synchronize()
@@ -196,7 +198,7 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["valu_roofline"]["frac"] = out["valu_roofline"]["achieved"] / out["valu_roofline"]["peak"]
-        out["cpu_baseline"] = cpu_baseline(args.log_height, args.log_blowup, job)
+        out["cpu_baseline"] = cpu_baseline(args.log_height, args.log_blowup, job, 1 if args.hash == "keccak" else 0)
     job.close()
     if rank == 0:
         print(json.dumps(out))

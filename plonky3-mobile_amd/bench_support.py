@@ -19,8 +19,9 @@ from .mmcs import MerkleTreeMmcs
 
 
 class _Worker(threading.Thread):
-    def __init__(self, device, log_height, params, stagger_s=0.0):
+    def __init__(self, device, log_height, params, stagger_s=0.0, hash="poseidon2"):
         super().__init__(daemon=True)
+        self.hash = hash
         self.stagger_s = stagger_s
         self.device, self.log_height, self.params = device, log_height, params
         self.inbox, self.outbox = queue.Queue(), queue.Queue()
@@ -30,7 +31,7 @@ class _Worker(threading.Thread):
     def run(self):
         try:
             torch.cuda.set_device(self.device)
-            self.prover = FibAirProver(self.log_height, params=self.params)
+            self.prover = FibAirProver(self.log_height, params=self.params, hash=self.hash)
             self.outbox.put(("ready", None))
         except Exception as e:  # surfaced by the caller
             self.outbox.put(("error", e))
@@ -68,8 +69,9 @@ class _Worker(threading.Thread):
 
 
 class FibAirJob:
-    def __init__(self, p3, log_height, log_blowup, batch, first_instance=0, threads=4):
+    def __init__(self, p3, log_height, log_blowup, batch, first_instance=0, threads=4, hash="poseidon2"):
         self.p3 = p3
+        self.hash = hash
         self.device = torch.cuda.current_device()
         self.log_height, self.log_blowup, self.batch = log_height, log_blowup, batch
         self.first = first_instance
@@ -79,7 +81,7 @@ class FibAirJob:
         self.params = FriParameters(log_blowup=log_blowup)
         self.threads = max(1, min(threads, batch))
         stag = float(os.environ.get("P3HIP_BENCH_STAGGER_MS", "1.0")) * 1e-3
-        self.workers = [_Worker(self.device, log_height, self.params, stag * t) for t in range(self.threads)]
+        self.workers = [_Worker(self.device, log_height, self.params, stag * t, hash) for t in range(self.threads)]
         for w in self.workers:
             w.result()
         self.last = None
@@ -95,6 +97,9 @@ class FibAirJob:
         return "proofs/s"
 
     def workload_name(self):
+        if self.hash == "keccak":
+            return ("fib_air 2^%d-row trace, BabyBear + the reference's own Keccak hashes (fib_air.rs:28-53, non-hiding), "
+                    "blowup %d" % (self.log_height, 1 << self.log_blowup))
         return "fib_air 2^%d-row trace, BabyBear+Poseidon2, blowup %d (BASELINE configs[1])" % (
             self.log_height, 1 << self.log_blowup)
 

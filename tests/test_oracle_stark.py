@@ -47,3 +47,19 @@ def test_benchmark_parameters_small(oracle):
     fp = oracle.FriParams()  # log_blowup 1, final poly len 1, 100 queries, 16 PoW bits
     proof = oracle.prove_fib_air(0, 1, 10, fp)
     assert oracle.verify_fib_air(proof, 0, 1, oracle.fib_public_x(0, 1, 1024), 10, fp) == 0
+
+
+def test_oracle_under_address_and_ub_sanitizers():
+    """The whole C restatement (both hash configurations, trees, transforms, every truncation of a proof) under
+    ASan + UBSan on the CPU: `make -C oracle sanitize` (GPU sanitizers are not available on the pool)."""
+    import os
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "sanitize"], capture_output=True, text=True, timeout=600)
+    if r.returncode != 0 and "cannot find -lasan" in r.stderr + r.stdout:
+        pytest.skip("libasan not installed")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "oracle selftest ok" in r.stdout

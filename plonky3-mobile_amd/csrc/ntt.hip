@@ -821,14 +821,17 @@ int lde_fused(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* ds
 }
 
 
-template <int B, int LQ, int K>
+template <int B, int LQ, int VW, int K>
 int launch_narrow_t(hipStream_t stream, const NarrowArgs& a, uint32_t blocks) {
-    // padded tile (17 rows per 16 points) + stage-table prefixes (K2: inverse and forward)
-    constexpr size_t lds = ((size_t)8 * narrow::lds_rows(B) << LQ) * (K == 2 ? NARROW_MID_TILES : 1) + ((size_t)4 << (B - 4)) * (K == 2 ? 2 : 1);
+    // padded tile (17 rows per 16 points; the middle kernel alternates two below 1024 threads) + stage-table prefixes
+    constexpr size_t tile_bytes = ((size_t)4 * VW * narrow::lds_rows(B)) << LQ;
+    constexpr size_t n_tiles = K == 2 ? (B - 4 + LQ >= 10 ? 1 : NARROW_MID_TILES) : 1;
+    constexpr size_t lds = tile_bytes * n_tiles + ((size_t)4 << (B - 4)) * (K == 2 ? 2 : 1);
+    static_assert(lds <= 160 * 1024, "narrow tile does not fit the LDS");
     void (*kern)(NarrowArgs);
-    if constexpr (K == 1) kern = narrow_inv1_kernel<B, LQ>;
-    else if constexpr (K == 2) kern = narrow_mid_kernel<B, LQ>;
-    else kern = narrow_fwd2_kernel<B, LQ>;
+    if constexpr (K == 1) kern = narrow_inv1_kernel<B, LQ, VW>;
+    else if constexpr (K == 2) kern = narrow_mid_kernel<B, LQ, VW>;
+    else kern = narrow_fwd2_kernel<B, LQ, VW>;
     if constexpr (lds > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -840,19 +843,23 @@ int launch_narrow_t(hipStream_t stream, const NarrowArgs& a, uint32_t blocks) {
     P3_HIP(hipGetLastError());
     return OK;
 }
-// slots per tile: 4 (32-byte row segments), 2 for 12-stage tiles: 64 KB of LDS and 512 threads, so that two
-// workgroups share a CU (one loads or stores while the other computes) and the middle kernel keeps 256 VGPRs
-constexpr int narrow_lq(int b, int k) { (void)k; return b == 12 ? 1 : 2; }
-template <int K>
-int launch_narrow(hipStream_t stream, const NarrowArgs& a, uint32_t b, uint32_t blocks) {
+// Geometry per digit size: column pairs per lane (VW = 2) or single columns (VW = 1: twice the waves; P3HIP_NTT_NARROW_VW).
+// Tile rows are 32 bytes (LQ = 2 for pairs, 3 for single words), 16 bytes for 12-stage digits (64 KB tiles, <= 1024 threads).
+constexpr int narrow_lq(int b, int vw) { return (b == 12 ? 1 : 2) + (vw == 1 ? 1 : 0); }
+template <int K, int VW>
+int launch_narrow_v(hipStream_t stream, const NarrowArgs& a, uint32_t b, uint32_t blocks) {
     switch (b) {
-        case 8: return launch_narrow_t<8, narrow_lq(8, K), K>(stream, a, blocks);
-        case 9: return launch_narrow_t<9, narrow_lq(9, K), K>(stream, a, blocks);
-        case 10: return launch_narrow_t<10, narrow_lq(10, K), K>(stream, a, blocks);
-        case 11: return launch_narrow_t<11, narrow_lq(11, K), K>(stream, a, blocks);
-        case 12: return launch_narrow_t<12, narrow_lq(12, K), K>(stream, a, blocks);
+        case 8: return launch_narrow_t<8, narrow_lq(8, VW), VW, K>(stream, a, blocks);
+        case 9: return launch_narrow_t<9, narrow_lq(9, VW), VW, K>(stream, a, blocks);
+        case 10: return launch_narrow_t<10, narrow_lq(10, VW), VW, K>(stream, a, blocks);
+        case 11: return launch_narrow_t<11, narrow_lq(11, VW), VW, K>(stream, a, blocks);
+        case 12: return launch_narrow_t<12, narrow_lq(12, VW), VW, K>(stream, a, blocks);
         default: return fail(ERR_INTERNAL, "lde_narrow: digit out of range");
     }
+}
+template <int K>
+int launch_narrow(hipStream_t stream, const NarrowArgs& a, uint32_t b, uint32_t blocks, int vw) {
+    return vw == 1 ? launch_narrow_v<K, 1>(stream, a, b, blocks) : launch_narrow_v<K, 2>(stream, a, b, blocks);
 }
 
 // Narrow-matrix coset LDE in three launches (ntt_narrow.cuh).  Returns 1 when the shape is not covered.
@@ -868,22 +875,35 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     if ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 7u) return 1;  // 8-byte accesses
     const uint32_t n1 = (n + 1) / 2, n2 = n - n1;
     const uint64_t N = 1ull << n;
+    // lane vector: column pairs, or single columns where that doubles a thin grid's waves per SIMD
+    static int force_vw = [] { const char* e = getenv("P3HIP_NTT_NARROW_VW"); return e ? atoi(e) : 0; }();
+    int vw[3];  // per kernel
+    // measured (tools/lde_sweep.py): single columns win by 15-25 % up to 2^19 rows (1-2 waves per SIMD otherwise), only
+    // for the middle kernel at 2^20 (26.5 -> 23.7 us), and lose from 2^21 on (the grid is full; twice the twiddle work)
+    for (int k = 0; k < 3; k++) vw[k] = force_vw == 1 || force_vw == 2 ? force_vw : (n <= 19 || (n == 20 && k == 1) ? 1 : 2);
     int rc = cx.ws[1].reserve(N * W * 4);
     if (rc) return rc;
     uint32_t* T = cx.ws[1].as<uint32_t>();
     NarrowArgs a{};
-    a.n = n; a.n1 = n1; a.n2 = n2; a.W = W; a.wsl = log2u(W / 2); a.added = added;
+    a.n = n; a.n1 = n1; a.n2 = n2; a.W = W; a.added = added;
     TwoLevelTable ti, tf;
     if ((rc = cx.get_root_table(n, true, &ti))) return rc;
     if ((rc = cx.get_root_table(n, false, &tf))) return rc;
-    const uint32_t wslots = W / 2;
+    auto geometry = [&](int k, uint32_t b, uint64_t rows) -> uint32_t {  // sets wsl / xcd_remap, returns the tile count
+        const uint32_t slots_per_row = W / vw[k];
+        a.wsl = log2u(slots_per_row);
+        const uint32_t lq = narrow_lq(b, vw[k]);
+        const uint32_t tiles = (uint32_t)((rows * slots_per_row) >> lq);
+        const uint32_t group = 8u << ((vw[k] == 2 ? 4 : 5) - lq);  // tiles per 128-byte line x 8 XCDs
+        a.xcd_remap = k != 2 && tiles % group == 0;
+        return tiles;
+    };
     // K1
     a.src = src; a.dst = T;
     a.stage_tw = cx.tile_tw[1];
     a.tw_lo = ti.lo; a.tw_hi = ti.hi; a.tw_T = ti.T;
-    uint32_t tiles = (uint32_t)(((1ull << n2) * wslots) >> narrow_lq(n1, 1));
-    a.xcd_remap = tiles % 64 == 0;
-    if ((rc = launch_narrow<1>(stream, a, n1, tiles))) return rc;
+    uint32_t tiles = geometry(0, n1, 1ull << n2);
+    if ((rc = launch_narrow<1>(stream, a, n1, tiles, vw[0]))) return rc;
     // K2
     a.src = T; a.dst = dst;
     a.stage_tw = cx.tile_tw[1]; a.stage_tw_fwd = cx.tile_tw[0];
@@ -898,15 +918,13 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
         a.sc_phi[j] = bb::pow(base, 1ull << (n1 + n2 - 4));
         base = bb::mul(base, g);
     }
-    tiles = (uint32_t)(((1ull << n1) * wslots) >> narrow_lq(n2, 2));
-    a.xcd_remap = tiles % 64 == 0;
-    if ((rc = launch_narrow<2>(stream, a, n2, tiles))) return rc;
+    tiles = geometry(1, n2, 1ull << n1);
+    if ((rc = launch_narrow<2>(stream, a, n2, tiles, vw[1]))) return rc;
     // K3
     a.src = dst; a.dst = dst;
     a.stage_tw = cx.tile_tw[0];
-    a.xcd_remap = 0;
-    tiles = (uint32_t)((((1ull << added) << n2) * wslots) >> narrow_lq(n1, 3));
-    return launch_narrow<3>(stream, a, n1, tiles);
+    tiles = geometry(2, n1, (1ull << added) << n2);
+    return launch_narrow<3>(stream, a, n1, tiles, vw[2]);
 }
 
 }  // namespace

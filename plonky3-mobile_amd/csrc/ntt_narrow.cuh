@@ -3,7 +3,8 @@
 // The general plans (ntt.hip / ntt_fast.cuh) move one 32-bit word per lane and cut 2^n rows into three 6-8 stage
 // digits per direction: five launches for 2^20 -> 2^21, every one re-reading and re-writing the matrix.  Here the
 // height is cut into TWO digits (n = n1 + n2, 8..12 stages each), a lane moves a PAIR of columns (8-byte
-// accesses, one twiddle serves both columns) and carries 16 points through radix-16 register rounds:
+// accesses, one twiddle serves both columns; single columns for the small heights, where twice the waves matter
+// more) and carries 16 points through radix-16 register rounds:
 //
 //   K1  narrow_inv1_kernel<n1>   x[r1*N2 + r2]  --DIF over r1, twiddle w^-(r2*k1)-->  T[r2*N1 + k1]   (transposed)
 //   K2  narrow_mid_kernel<n2>    T[r2*N1 + k1]  --DIF over r2--> c[k1 + N1*k2]  (coefficients stay on chip), then for
@@ -37,7 +38,7 @@ namespace p3 {
 struct NarrowArgs {
     const uint32_t* src;
     uint32_t* dst;
-    uint32_t n, n1, n2, W, wsl;   // wsl = log2(W / 2): 8-byte slots per row
+    uint32_t n, n1, n2, W, wsl;   // wsl = log2(W / VW): slots (lane vectors of VW words) per row
     uint32_t added;
     const uint32_t* stage_tw;     // this kernel's direction: stage u at offset 2^u - 1 (reference layout, 12 stages)
     const uint32_t* stage_tw_fwd; // K2: forward table
@@ -57,6 +58,16 @@ struct NarrowArgs {
 namespace narrow {
 
 
+// element vector of a lane: VW = 2 columns (uint2, 8-byte accesses) or VW = 1 (uint32_t: twice the lanes and waves for
+// the same matrix — on CDNA a SIMD needs >= 2-4 resident waves to reach its VALU issue rate, and the small LDEs
+// have only 1-2 waves per SIMD with column pairs)
+template <int VW> struct Vec;
+template <> struct Vec<1> { using T = uint32_t; };
+template <> struct Vec<2> { using T = uint2; };
+__device__ __forceinline__ uint32_t add2(uint32_t a, uint32_t b) { return bb::add(a, b); }
+__device__ __forceinline__ uint32_t sub2(uint32_t a, uint32_t b) { return bb::sub(a, b); }
+__device__ __forceinline__ uint32_t subl2(uint32_t a, uint32_t b) { return a - b + bb::P; }
+__device__ __forceinline__ uint32_t mul2(uint32_t a, uint32_t w) { return bb::mul(a, w); }
 __device__ __forceinline__ uint2 add2(uint2 a, uint2 b) { return make_uint2(bb::add(a.x, b.x), bb::add(a.y, b.y)); }
 __device__ __forceinline__ uint2 sub2(uint2 a, uint2 b) { return make_uint2(bb::sub(a.x, b.x), bb::sub(a.y, b.y)); }
 // a - b + P in (0, 2P): a valid (unreduced) operand of the Montgomery product
@@ -86,8 +97,8 @@ constexpr uint32_t lds_rows(int B) { return (1u << B) + (1u << (B - 4)); }
 
 // DIF stages UHI-1 .. ULO on the registers (window at bit A); stage u pairs points differing in bit u:
 // (a, b) -> (a + b, (a - b) * w_{2^(u+1)}^(pt mod 2^u))   [stage semantics of backend_vulkan.rs:881-942, DIF form]
-template <int A, int UHI, int ULO>
-__device__ __forceinline__ void stage_block(uint2 (&v)[16], const uint32_t* __restrict__ tw, uint32_t t) {
+template <int A, int UHI, int ULO, class V>
+__device__ __forceinline__ void stage_block(V (&v)[16], const uint32_t* __restrict__ tw, uint32_t t) {
     const uint32_t tlo = t & ((1u << A) - 1u);
 #pragma unroll
     for (int u = UHI - 1; u >= ULO; --u) {
@@ -102,7 +113,7 @@ __device__ __forceinline__ void stage_block(uint2 (&v)[16], const uint32_t* __re
         for (int j0 = 0; j0 < 16; j0++) {
             if ((j0 >> d) & 1) continue;
             const int j1 = j0 | (1 << d);
-            const uint2 x = v[j0], y = v[j1];
+            const V x = v[j0], y = v[j1];
             v[j0] = add2(x, y);
             if (u == 0) v[j1] = sub2(x, y);
             else v[j1] = mul2(subl2(x, y), w[j0 & ((1 << d) - 1)]);
@@ -119,14 +130,15 @@ __device__ __forceinline__ void load_round1_twiddles(const uint32_t* __restrict_
 #pragma unroll
         for (int jl = 0; jl < (1 << d); jl++) w1[(1 << d) - 1 + jl] = tw[(1u << (B - 4 + d)) - 1u + (t | ((uint32_t)jl << (B - 4)))];
 }
-__device__ __forceinline__ void stage_block_round1(uint2 (&v)[16], const uint32_t (&w1)[15]) {
+template <class V>
+__device__ __forceinline__ void stage_block_round1(V (&v)[16], const uint32_t (&w1)[15]) {
 #pragma unroll
     for (int d = 3; d >= 0; --d) {
 #pragma unroll
         for (int j0 = 0; j0 < 16; j0++) {
             if ((j0 >> d) & 1) continue;
             const int j1 = j0 | (1 << d);
-            const uint2 x = v[j0], y = v[j1];
+            const V x = v[j0], y = v[j1];
             v[j0] = add2(x, y);
             v[j1] = mul2(subl2(x, y), w1[(1 << d) - 1 + (j0 & ((1 << d) - 1))]);
         }
@@ -137,33 +149,34 @@ __device__ __forceinline__ void stage_block_round1(uint2 (&v)[16], const uint32_
 // the writes and the reads): the tile written now was last read two hand-overs ago, and the barrier of the
 // hand-over in between already separates those reads from these writes.  With one tile (a == b) every hand-over
 // also waits, before writing, for the previous one's reads.
+template <class V>
 struct Tiles {
-    uint2* a;
-    uint2* b;
-    __device__ __forceinline__ uint2* next() {
-        if (a != b) { uint2* r = a; a = b; b = r; return r; }
+    V* a;
+    V* b;
+    __device__ __forceinline__ V* next() {
+        if (a != b) { V* r = a; a = b; b = r; return r; }
         __syncthreads();
         return a;
     }
 };
 
 // registers (window AF) -> LDS -> registers (window AT)
-template <int LQ, int AF, int AT>
-__device__ __forceinline__ void exchange(Tiles& tiles, uint2 (&v)[16], uint32_t t, uint32_t q) {
-    uint2* tile = tiles.next();
-    uint2* wp = tile + lds_base<LQ, AF>(t, q);
+template <int LQ, int AF, int AT, class V>
+__device__ __forceinline__ void exchange(Tiles<V>& tiles, V (&v)[16], uint32_t t, uint32_t q) {
+    V* tile = tiles.next();
+    V* wp = tile + lds_base<LQ, AF>(t, q);
 #pragma unroll
     for (uint32_t j = 0; j < 16; j++) wp[lds_joff<LQ>(j << AF)] = v[j];
     __syncthreads();
-    const uint2* rp = tile + lds_base<LQ, AT>(t, q);
+    const V* rp = tile + lds_base<LQ, AT>(t, q);
 #pragma unroll
     for (uint32_t j = 0; j < 16; j++) v[j] = rp[lds_joff<LQ>(j << AT)];
 }
 
 // B-stage DIF of the tile: in: v[j] = point pt_of<B-4>(t, j) (natural order); out: v[j] = position pt_of<0>(t, j),
 // which holds frequency rev_B(position).  twl: stage table in LDS (stages below B-4 at least).
-template <int B, int LQ>
-__device__ __forceinline__ void dif_rounds_after1(uint2 (&v)[16], Tiles& tile, const uint32_t* twl, uint32_t t, uint32_t q) {
+template <int B, int LQ, class V>
+__device__ __forceinline__ void dif_rounds_after1(V (&v)[16], Tiles<V>& tile, const uint32_t* twl, uint32_t t, uint32_t q) {
     constexpr int A1 = B - 4, A2 = B > 8 ? B - 8 : 0;
     exchange<LQ, A1, A2>(tile, v, t, q);
     stage_block<A2, A1, A2>(v, twl, t);
@@ -172,53 +185,55 @@ __device__ __forceinline__ void dif_rounds_after1(uint2 (&v)[16], Tiles& tile, c
         stage_block<0, A2, 0>(v, twl, t);
     }
 }
-template <int B, int LQ>
-__device__ __forceinline__ void dif_rounds(uint2 (&v)[16], Tiles& tile, const uint32_t (&w1)[15], const uint32_t* twl, uint32_t t, uint32_t q) {
+template <int B, int LQ, class V>
+__device__ __forceinline__ void dif_rounds(V (&v)[16], Tiles<V>& tile, const uint32_t (&w1)[15], const uint32_t* twl, uint32_t t, uint32_t q) {
     stage_block_round1(v, w1);
     dif_rounds_after1<B, LQ>(v, tile, twl, t, q);
 }
 // registers in final layout (position pt_of<0>) -> LDS row = frequency rev_B(position) = (rev4(j) << (B-4)) | rev(t)
 // -> registers in the first layout (row pt_of<B-4>): natural frequency order, 16 consecutive rows per 16 lanes.
-template <int B, int LQ>
-__device__ __forceinline__ void to_natural(Tiles& tiles, uint2 (&v)[16], uint32_t t, uint32_t q) {
-    uint2* tile = tiles.next();
+template <int B, int LQ, class V>
+__device__ __forceinline__ void to_natural(Tiles<V>& tiles, V (&v)[16], uint32_t t, uint32_t q) {
+    V* tile = tiles.next();
     const uint32_t rt = rev_bits(t, B - 4);
-    uint2* wp = tile + (((rt + (rt >> 4)) << LQ) + q);
+    V* wp = tile + (((rt + (rt >> 4)) << LQ) + q);
 #pragma unroll
     for (uint32_t j = 0; j < 16; j++) wp[lds_joff<LQ>(crev(j, 4) << (B - 4))] = v[j];
     __syncthreads();
-    const uint2* rp = tile + lds_base<LQ, B - 4>(t, q);
+    const V* rp = tile + lds_base<LQ, B - 4>(t, q);
 #pragma unroll
     for (uint32_t j = 0; j < 16; j++) v[j] = rp[lds_joff<LQ>(j << (B - 4))];
 }
 // same hand-over without the bit reversal (K3: position order is already the wanted order)
-template <int B, int LQ>
-__device__ __forceinline__ void to_rows(Tiles& tile, uint2 (&v)[16], uint32_t t, uint32_t q) {
+template <int B, int LQ, class V>
+__device__ __forceinline__ void to_rows(Tiles<V>& tile, V (&v)[16], uint32_t t, uint32_t q) {
     exchange<LQ, 0, B - 4>(tile, v, t, q);
 }
 
 // Adjacent tiles (four of them for 32-byte segments) share 128-byte lines of the strided side: keep them on one XCD (workgroups are dealt to
 // the 8 XCDs round-robin by blockIdx) so the line is fetched into one L2 only.
-template <int LQ>
+template <int LQ, int VW>
 __device__ __forceinline__ uint32_t tile_of_block(uint32_t bid, uint32_t remap) {
     if (!remap) return bid;
-    constexpr uint32_t LG = 4 - LQ;  // log2(tiles per 128-byte line)
+    constexpr uint32_t LG = (VW == 2 ? 4 : 5) - LQ;  // log2(tiles per 128-byte line)
     const uint32_t xcd = bid & 7u, s = bid >> 3;
     return ((s >> LG) << (LG + 3)) | (xcd << LG) | (s & ((1u << LG) - 1u));
 }
 
 // Global accesses as UNIFORM base + 32-bit per-lane byte offset (global_load/store ... saddr): the sixteen row
 // offsets of a lane's points are uniform, so they live in SGPRs instead of sixteen 64-bit VGPR addresses.
-__device__ __forceinline__ uint2 ld2(const void* base, uint32_t off) {
-    return *reinterpret_cast<const uint2*>(static_cast<const char*>(base) + off);
+template <class V>
+__device__ __forceinline__ V ldv(const void* base, uint32_t off) {
+    return *reinterpret_cast<const V*>(static_cast<const char*>(base) + off);
 }
-__device__ __forceinline__ void st2(void* base, uint32_t off, uint2 v) {
-    *reinterpret_cast<uint2*>(static_cast<char*>(base) + off) = v;
+template <class V>
+__device__ __forceinline__ void stv(void* base, uint32_t off, V v) {
+    *reinterpret_cast<V*>(static_cast<char*>(base) + off) = v;
 }
 
 // v[j] *= c * phi^(idx(j)), idx(j) = REV ? rev4(j) : j
-template <bool REV>
-__device__ __forceinline__ void scale_ladder(uint2 (&v)[16], uint32_t c, uint32_t phi) {
+template <bool REV, class V>
+__device__ __forceinline__ void scale_ladder(V (&v)[16], uint32_t c, uint32_t phi) {
     uint32_t pw[16];
     power_ladder<16>(c, phi, pw);
 #pragma unroll
@@ -228,21 +243,22 @@ __device__ __forceinline__ void scale_ladder(uint2 (&v)[16], uint32_t c, uint32_
 }  // namespace narrow
 
 // K1: first inverse digit (the high n1 bits of the row index), transposed store.
-template <int B, int LQ>
+template <int B, int LQ, int VW>
 __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow_inv1_kernel(NarrowArgs a) {
     using namespace narrow;
+    using V = typename Vec<VW>::T;
     constexpr uint32_t NQ = 1u << LQ, NTH = 1u << (B - 4 + LQ);
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    Tiles tile{reinterpret_cast<uint2*>(smem), reinterpret_cast<uint2*>(smem)};
-    uint32_t* twl = smem + (2u * lds_rows(B) << LQ);                                // stages below B-4: 2^(B-4) - 1 words
+    Tiles<V> tile{reinterpret_cast<V*>(smem), reinterpret_cast<V*>(smem)};
+    uint32_t* twl = smem + (VW * lds_rows(B) << LQ);                       // stages below B-4: 2^(B-4) - 1 words
     const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> LQ;
-    const uint32_t s = tile_of_block<LQ>(blockIdx.x, a.xcd_remap) * NQ + q;  // 8-byte slot within a row group of N2 rows
+    const uint32_t s = tile_of_block<LQ, VW>(blockIdx.x, a.xcd_remap) * NQ + q;  // slot (VW words) within a row group of N2 rows
     const uint32_t lo = s >> a.wsl, cp = s & ((1u << a.wsl) - 1u);
     const uint32_t rowstride = a.W << a.n2;                               // words between r1 and r1 + 1
-    const uint32_t ld_off = (2u * s + t * rowstride) * 4u;
-    uint2 v[16];
+    const uint32_t ld_off = (VW * s + t * rowstride) * 4u;
+    V v[16];
 #pragma unroll
-    for (uint32_t j = 0; j < 16; j++) v[j] = ld2(a.src + ((uint64_t)j << (B - 4)) * rowstride, ld_off);
+    for (uint32_t j = 0; j < 16; j++) v[j] = ldv<V>(a.src + ((uint64_t)j << (B - 4)) * rowstride, ld_off);
     uint32_t w1[15];
     load_round1_twiddles<B>(a.stage_tw, t, w1);
     for (uint32_t i = threadIdx.x; i + 1 < (1u << (B - 4)); i += NTH) twl[i] = a.stage_tw[i];
@@ -252,31 +268,33 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow_inv1_kernel(NarrowAr
     dif_rounds<B, LQ>(v, tile, w1, twl, t, q);
     scale_ladder<true>(v, c, phi);
     to_natural<B, LQ>(tile, v, t, q);
-    // T[(lo * N1 + k1) * W + 2 cp], k1 = pt_of<B-4>(t, j): 16 lanes x 8 bytes contiguous per (lo, cp)
-    const uint32_t st_off = (((lo << B) + t) * a.W + 2u * cp) * 4u;
+    // T[(lo * N1 + k1) * W + VW cp], k1 = pt_of<B-4>(t, j): consecutive lanes (cp, then k1) are contiguous for W <= NQ * VW
+    const uint32_t st_off = (((lo << B) + t) * a.W + VW * cp) * 4u;
 #pragma unroll
-    for (uint32_t j = 0; j < 16; j++) st2(a.dst + ((uint64_t)j << (B - 4)) * a.W, st_off, v[j]);
+    for (uint32_t j = 0; j < 16; j++) stv<V>(a.dst + ((uint64_t)j << (B - 4)) * a.W, st_off, v[j]);
 }
 
 // K2: second inverse digit, then per coset: scale, first forward digit, twiddle, strided store.
-template <int B, int LQ>
+template <int B, int LQ, int VW>
 __global__ void __launch_bounds__(1 << (B - 4 + LQ), (B - 4 + LQ >= 9 && NARROW_MID_SHARE_CU) ? 4 : 1) narrow_mid_kernel(NarrowArgs a) {
     using namespace narrow;
+    using V = typename Vec<VW>::T;
     constexpr uint32_t NQ = 1u << LQ, NTH = 1u << (B - 4 + LQ);
-    constexpr bool LEAN = NTH >= 512;  // 128 VGPRs per lane: rebuild the output ladder per coset
+    constexpr bool LEAN = NTH >= 512;  // at most 256 (1024 threads: 128) VGPRs per lane: rebuild the output ladder per coset
+    constexpr uint32_t NT = NTH >= 1024 ? 1 : NARROW_MID_TILES;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // two tiles (one barrier per hand-over): the 15 hand-overs of a blowup-4 middle pass are this kernel's stalls
-    Tiles tile{reinterpret_cast<uint2*>(smem), reinterpret_cast<uint2*>(smem) + (NARROW_MID_TILES - 1) * (lds_rows(B) << LQ)};
-    uint32_t* twl_i = smem + (NARROW_MID_TILES * 2u * lds_rows(B) << LQ);   // inverse stages below B-4
-    uint32_t* twl_f = twl_i + (1u << (B - 4)); // forward stages below B-4
+    Tiles<V> tile{reinterpret_cast<V*>(smem), reinterpret_cast<V*>(smem) + (NT - 1) * (lds_rows(B) << LQ)};
+    uint32_t* twl_i = smem + (NT * VW * lds_rows(B) << LQ);   // inverse stages below B-4
+    uint32_t* twl_f = twl_i + (1u << (B - 4));                // forward stages below B-4
     const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> LQ;
-    const uint32_t s = tile_of_block<LQ>(blockIdx.x, a.xcd_remap) * NQ + q;  // slot within a group of N1 rows
+    const uint32_t s = tile_of_block<LQ, VW>(blockIdx.x, a.xcd_remap) * NQ + q;  // slot within a group of N1 rows
     const uint32_t k1 = s >> a.wsl;
     const uint32_t rowstride = a.W << a.n1;
-    const uint32_t ld_off = (2u * s + t * rowstride) * 4u, st_off = (2u * s + (t << 4) * rowstride) * 4u;
-    uint2 c[16];
+    const uint32_t ld_off = (VW * s + t * rowstride) * 4u, st_off = (VW * s + (t << 4) * rowstride) * 4u;
+    V c[16];
 #pragma unroll
-    for (uint32_t j = 0; j < 16; j++) c[j] = ld2(a.src + ((uint64_t)j << (B - 4)) * rowstride, ld_off);
+    for (uint32_t j = 0; j < 16; j++) c[j] = ldv<V>(a.src + ((uint64_t)j << (B - 4)) * rowstride, ld_off);
     {
         uint32_t w1[15];
         load_round1_twiddles<B>(a.stage_tw, t, w1);
@@ -298,7 +316,7 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ), (B - 4 + LQ >= 9 && NARROW_
         if (jc + 1 < ncos) sc_next = two_level(a.sc_lo[jc + 1], a.sc_hi[jc + 1], a.sc_T, kbase);
         uint32_t w1[15];  // in flight while the scale ladder runs
         load_round1_twiddles<B>(a.stage_tw_fwd, t, w1);
-        uint2 v[16];
+        V v[16];
 #pragma unroll
         for (uint32_t j = 0; j < 16; j++) v[j] = c[j];
         scale_ladder<false>(v, sc, a.sc_phi[jc]);
@@ -307,37 +325,38 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ), (B - 4 + LQ >= 9 && NARROW_
         if constexpr (LEAN) {
             scale_ladder<true>(v, c0, phi0);
 #pragma unroll
-            for (uint32_t j = 0; j < 16; j++) st2(o + (uint64_t)j * rowstride, st_off, v[j]);
+            for (uint32_t j = 0; j < 16; j++) stv<V>(o + (uint64_t)j * rowstride, st_off, v[j]);
         } else {
 #pragma unroll
-            for (uint32_t j = 0; j < 16; j++) st2(o + (uint64_t)j * rowstride, st_off, mul2(v[j], pw2[crev(j, 4)]));
+            for (uint32_t j = 0; j < 16; j++) stv<V>(o + (uint64_t)j * rowstride, st_off, mul2(v[j], pw2[crev(j, 4)]));
         }
     }
 }
 
 // K3: last forward digit on contiguous blocks of 2^B rows, in place.
-template <int B, int LQ>
+template <int B, int LQ, int VW>
 __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow_fwd2_kernel(NarrowArgs a) {
     using namespace narrow;
+    using V = typename Vec<VW>::T;
     constexpr uint32_t NQ = 1u << LQ, NTH = 1u << (B - 4 + LQ);
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    Tiles tile{reinterpret_cast<uint2*>(smem), reinterpret_cast<uint2*>(smem)};
-    uint32_t* twl = smem + (2u * lds_rows(B) << LQ);
+    Tiles<V> tile{reinterpret_cast<V*>(smem), reinterpret_cast<V*>(smem)};
+    uint32_t* twl = smem + (VW * lds_rows(B) << LQ);
     const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> LQ;
     const uint32_t s = blockIdx.x * NQ + q;
     const uint32_t blk0 = (blockIdx.x * NQ) >> a.wsl, blk = s >> a.wsl, cp = s & ((1u << a.wsl) - 1u);
     uint32_t* p = a.dst + ((uint64_t)blk0 << B) * a.W;                    // uniform: the workgroup's first block
-    const uint32_t off = ((((blk - blk0) << B) + t) * a.W + 2u * cp) * 4u;
-    uint2 v[16];
+    const uint32_t off = ((((blk - blk0) << B) + t) * a.W + VW * cp) * 4u;
+    V v[16];
 #pragma unroll
-    for (uint32_t j = 0; j < 16; j++) v[j] = ld2(p + ((uint64_t)j << (B - 4)) * a.W, off);
+    for (uint32_t j = 0; j < 16; j++) v[j] = ldv<V>(p + ((uint64_t)j << (B - 4)) * a.W, off);
     uint32_t w1[15];
     load_round1_twiddles<B>(a.stage_tw, t, w1);
     for (uint32_t i = threadIdx.x; i + 1 < (1u << (B - 4)); i += NTH) twl[i] = a.stage_tw[i];
     dif_rounds<B, LQ>(v, tile, w1, twl, t, q);
     to_rows<B, LQ>(tile, v, t, q);
 #pragma unroll
-    for (uint32_t j = 0; j < 16; j++) st2(p + ((uint64_t)j << (B - 4)) * a.W, off, v[j]);
+    for (uint32_t j = 0; j < 16; j++) stv<V>(p + ((uint64_t)j << (B - 4)) * a.W, off, v[j]);
 }
 
 }  // namespace p3

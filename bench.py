@@ -112,7 +112,7 @@ def main():
     from plonky3_mobile_amd import batch as pbatch
     n_total = args.batch * world
 
-    coll_state = {"mode": "rccl scatter/gather" if world > 1 else "none (single rank)"}
+    coll_state = {"mode": ("rccl scatter/gather" if backend == "nccl" else backend + " scatter/gather (rehearsal)") if world > 1 else "none (single rank)"}
     if os.environ.get("P3HIP_BENCH_NO_GATHER"):
         coll_state["mode"] = "disabled by P3HIP_BENCH_NO_GATHER: local sharding only"
 
@@ -121,24 +121,34 @@ def main():
             return job.step()
         # BASELINE configs[3]: rank 0 scatters the instance descriptors, every rank proves its shard
         # (instance i -> rank i mod world), the proof bytes are gathered back on rank 0.  No other collective.
-        if coll_state["mode"].startswith("rccl"):
+        if "scatter/gather" in coll_state["mode"] and not coll_state["mode"].startswith("fallback"):
             try:
                 inst = [(k * n_total + i, k * n_total + i + 1) for i in range(n_total)] if rank == 0 else []
                 mine = pbatch.scatter_descriptors(inst, device=coll_dev)
                 got = job.step([(i, a) for i, a, _ in mine])
-                return pbatch.gather_proofs(sorted(got.items()), n_total, device=coll_dev)
+                # the gather of this step's proofs overlaps the next step's proving; the previous one is collected now
+                prev, coll_state["pending"] = coll_state.get("pending"), pbatch.gather_proofs_async(
+                    sorted(got.items()), n_total, device=coll_dev)
+                return prev.wait() if prev is not None else None
             except Exception as e:  # keep the scaling run alive: the sharding itself needs no collective
                 coll_state["mode"] = "fallback to local sharding (collective failed: %s)" % type(e).__name__
                 print("bench.py: scatter/gather failed on rank %d: %r" % (rank, e), file=sys.stderr)
         mine = [(i, k * n_total + i) for i in pbatch.shard_instances(n_total, rank, world)]
         return job.step(mine)
 
+    def drain():
+        pend = coll_state.pop("pending", None)
+        if pend is not None:
+            pend.wait()
+
     for k in range(args.warmup):
         one_step(k)
+    drain()
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         one_step(args.warmup + k)
+    drain()  # the last step's proofs must be on rank 0 inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:

@@ -33,29 +33,49 @@ def scatter_descriptors(instances, device="cpu"):
     return [(int(i), int(a), int(b)) for i, a, b in recv.cpu().tolist() if i >= 0]
 
 
-def gather_proofs(local, n_total, device="cpu"):
-    """local: list of (index, proof bytes) of this rank.  Returns on rank 0 the list of all n_total proofs in
-    instance order (None elsewhere).  Proofs are padded to the longest one for a fixed-size all_gather."""
+class _PendingGather:
+    """An in-flight gather of one step's proofs (two async collectives); wait() returns the proofs on rank 0."""
+
+    def __init__(self, works, bufs, metas, n_total, keep):
+        self.works, self.bufs, self.metas, self.n_total, self.keep = works, bufs, metas, n_total, keep
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        if self.bufs is None:
+            return None
+        out = [None] * self.n_total
+        for b, m in zip(self.bufs, self.metas):
+            b, m = b.cpu().numpy(), m.cpu().tolist()
+            for k, (i, ln) in enumerate(m):
+                if i >= 0:
+                    out[i] = b[k, :ln].tobytes()
+        return out
+
+
+def gather_proofs_async(local, n_total, device="cpu"):
+    """local: list of (index, proof bytes) of this rank.  Starts the gather to rank 0 and returns a handle whose
+    wait() gives, on rank 0, all n_total proofs in instance order (None elsewhere).  Proofs are staged in one host
+    buffer padded to the longest one (a single H2D copy), so the collective has a fixed shape; being asynchronous
+    it overlaps the next step's proving."""
     world, rank = dist.get_world_size(), dist.get_rank()
     per = (n_total + world - 1) // world
     max_len = torch.tensor([max([len(p) for _, p in local], default=0)], dtype=torch.int64, device=device)
     dist.all_reduce(max_len, op=dist.ReduceOp.MAX)
     width = int(max_len.item())
-    buf = torch.zeros((per, width), dtype=torch.uint8, device=device)
-    meta = torch.full((per, 2), -1, dtype=torch.int64, device=device)  # (instance index, length)
+    host = np.zeros((per, width), dtype=np.uint8)
+    hmeta = np.full((per, 2), -1, dtype=np.int64)  # (instance index, length)
     for k, (i, p) in enumerate(local):
-        buf[k, : len(p)] = torch.from_numpy(np.frombuffer(p, dtype=np.uint8).copy()).to(device)
-        meta[k, 0], meta[k, 1] = i, len(p)
+        host[k, : len(p)] = np.frombuffer(p, dtype=np.uint8)
+        hmeta[k] = (i, len(p))
+    buf = torch.from_numpy(host).to(device)
+    meta = torch.from_numpy(hmeta).to(device)
     bufs = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
     metas = [torch.empty_like(meta) for _ in range(world)] if rank == 0 else None
-    dist.gather(buf, bufs, dst=0)
-    dist.gather(meta, metas, dst=0)
-    if rank != 0:
-        return None
-    out = [None] * n_total
-    for b, m in zip(bufs, metas):
-        b, m = b.cpu().numpy(), m.cpu().tolist()
-        for k, (i, ln) in enumerate(m):
-            if i >= 0:
-                out[i] = b[k, :ln].tobytes()
-    return out
+    works = [dist.gather(buf, bufs, dst=0, async_op=True), dist.gather(meta, metas, dst=0, async_op=True)]
+    return _PendingGather(works, bufs, metas, n_total, (buf, meta))
+
+
+def gather_proofs(local, n_total, device="cpu"):
+    """Synchronous form of gather_proofs_async."""
+    return gather_proofs_async(local, n_total, device).wait()

@@ -53,6 +53,28 @@ class _PendingGather:
         return out
 
 
+_STAGING = {}
+
+
+def _staging(per, width, device):
+    """Two alternating (pinned host, device) staging pairs per shape: the previous step's gather may still be
+    reading one while the next step fills the other."""
+    key = (per, width, str(device))
+    ent = _STAGING.get(key)
+    if ent is None:
+        pairs = []
+        for _ in range(2):
+            h = torch.zeros((per, width), dtype=torch.uint8)
+            if str(device) != "cpu":
+                h = h.pin_memory()
+                pairs.append((h, torch.empty((per, width), dtype=torch.uint8, device=device)))
+            else:
+                pairs.append((h, h))
+        ent = _STAGING[key] = {"pairs": pairs, "turn": 0}
+    ent["turn"] ^= 1
+    return ent["pairs"][ent["turn"]]
+
+
 def gather_proofs_async(local, n_total, device="cpu"):
     """local: list of (index, proof bytes) of this rank.  Starts the gather to rank 0 and returns a handle whose
     wait() gives, on rank 0, all n_total proofs in instance order (None elsewhere).  Proofs are staged in one host
@@ -63,12 +85,16 @@ def gather_proofs_async(local, n_total, device="cpu"):
     max_len = torch.tensor([max([len(p) for _, p in local], default=0)], dtype=torch.int64, device=device)
     dist.all_reduce(max_len, op=dist.ReduceOp.MAX)
     width = int(max_len.item())
-    host = np.zeros((per, width), dtype=np.uint8)
+    hbuf, buf = _staging(per, width, device)
+    host = hbuf.numpy()
     hmeta = np.full((per, 2), -1, dtype=np.int64)  # (instance index, length)
     for k, (i, p) in enumerate(local):
         host[k, : len(p)] = np.frombuffer(p, dtype=np.uint8)
+        host[k, len(p):] = 0
         hmeta[k] = (i, len(p))
-    buf = torch.from_numpy(host).to(device)
+    host[len(local):] = 0
+    if buf is not hbuf:
+        buf.copy_(hbuf, non_blocking=True)  # pinned -> device, ordered before the collective on the current stream
     meta = torch.from_numpy(hmeta).to(device)
     bufs = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
     metas = [torch.empty_like(meta) for _ in range(world)] if rank == 0 else None

@@ -222,3 +222,15 @@ def test_narrow_three_launch_lde(dft, oracle, p3, log_h, w, ab):
     exp = oracle.coset_lde_batch(x, ab, shift, True)
     got = dft.coset_lde_batch(x, ab, shift, bit_reversed_out=True)
     assert np.array_equal(got, exp)
+
+
+def test_raw_u32_plan_entry_like_the_reference_benchmark(p3, oracle):
+    """prepare_compute_plan(width, height, 0, log_n) + setup_pipeline_plan(&plan, &[u32]) as the reference's benchmark
+    drives them (fib_air.rs:128-134): natural-order Montgomery words in and out."""
+    for h, w in [(256, 8), (4096, 32), (1024, 3)]:
+        x = oracle.benchmark_input(h, w) if hasattr(oracle, "benchmark_input") else _rand(np.random.default_rng(h), h, w)
+        plan = p3.plan.prepare_compute_plan(w, h, 0, h.bit_length() - 1)
+        got = p3.plan.setup_pipeline_plan(plan, np.asarray(x, dtype=np.uint32).reshape(-1))
+        assert np.array_equal(got.reshape(h, w), oracle.dft_batch(np.asarray(x, dtype=np.uint32).reshape(h, w)))
+    with pytest.raises(ValueError):
+        p3.plan.setup_pipeline_plan(p3.plan.prepare_compute_plan(4, 8, 0, 3), np.zeros(5, dtype=np.uint32))

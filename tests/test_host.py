@@ -98,3 +98,31 @@ def test_product_verifier_keccak_configuration(p3, oracle):
                 p3.verify_fib_air(bad.tobytes(), 3, 4, x, log_n, gfp, hash="keccak")
     with pytest.raises(ValueError):
         p3.verify_fib_air(proof, 3, 4, x, log_n, gfp, hash="sha2")
+
+
+def test_plan_helpers_mirror_reference_layouts(p3, oracle):
+    """FftStageParams / prepare_compute_plan / twiddle_table / bit-reversed rows (backend_vulkan.rs:784-1026): host
+    integer code, checked against the oracle's statement of the same layouts."""
+    import numpy as np
+    pl = p3.plan
+    prm = pl.params_for_stage(8, 1024, 3, 10, 7)
+    assert len(prm.pack()) == 32 and prm.pack()[:20] == np.array([8, 1024, 3, 10, 7], dtype="<u4").tobytes()
+    plan = pl.prepare_compute_plan(128, 16384, 0, 14)
+    assert plan.params.twiddle_base == 1 and plan.dispatch == (16, 1024, 1)
+    # the dispatch y of a 2^20-row stage exceeds Vulkan's guaranteed 65535 (SURVEY.md §8a R8): here it is just a number
+    assert pl.prepare_compute_plan(2, 1 << 20, 0, 20).dispatch[1] == 65536
+    for log_n in (0, 1, 4, 9):
+        tab = pl.twiddle_table(log_n)
+        assert tab.size == (1 << log_n) - 1 if log_n else tab.size == 0
+        if log_n:
+            L = oracle.lib()
+            exp = np.zeros((1 << log_n) - 1, dtype=np.uint32)
+            L.p3o_twiddle_table(log_n, exp.ctypes.data_as(oracle._u32p))
+            assert np.array_equal(tab, exp)
+            assert all(np.array_equal(tab[(1 << s) - 1:(1 << (s + 1)) - 1], pl.twiddles_for_stage(log_n, s)) for s in range(log_n))
+    assert pl.two_adic_generator(27) == 0x1a427a41
+    rng = np.random.default_rng(2)
+    x = rng.integers(0, 0x78000001, (64, 3), dtype=np.uint32)
+    assert np.array_equal(pl.write_bit_reversed_rows_u32(x.reshape(-1), 3).reshape(64, 3), oracle.bit_reverse_rows(x))
+    assert np.array_equal(pl.write_bit_reversed_rows_u32(x[:24].reshape(-1), 3), x[:24].reshape(-1))  # 24 rows: copied
+    assert [pl.reverse_bits_len(i, 3) for i in range(8)] == [0, 4, 2, 6, 1, 5, 3, 7]

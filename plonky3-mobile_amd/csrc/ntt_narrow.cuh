@@ -30,6 +30,13 @@
 #ifndef NARROW_MID_TILES
 #define NARROW_MID_TILES 2  // LDS tiles of the middle kernel (1 or 2)
 #endif
+#ifndef NARROW_MID_SEQ
+#define NARROW_MID_SEQ 0  // experiment: column-sequential coset loop for the 512-thread pair tiles (measured 2x SLOWER:
+                          // the compiler spills ~85 registers at the 128-VGPR cap; 2^24 middle pass 549 -> 1063 us)
+#endif
+#ifndef NARROW_MID_SEQ_WAVES
+#define NARROW_MID_SEQ_WAVES 4
+#endif
 #ifndef NARROW_MID_SHARE_CU
 #define NARROW_MID_SHARE_CU 0
 #endif
@@ -147,22 +154,22 @@ __device__ __forceinline__ void stage_block_round1(V (&v)[16], const uint32_t (&
 
 // One or two LDS tiles.  With two, consecutive hand-overs alternate between them and need ONE barrier each (between
 // the writes and the reads): the tile written now was last read two hand-overs ago, and the barrier of the
-// hand-over in between already separates those reads from these writes.  With one tile (a == b) every hand-over
+// hand-over in between already separates those reads from these writes.  With one tile (TWO = false) every hand-over
 // also waits, before writing, for the previous one's reads.
-template <class V>
+template <class V, bool TWO>
 struct Tiles {
     V* a;
     V* b;
     __device__ __forceinline__ V* next() {
-        if (a != b) { V* r = a; a = b; b = r; return r; }
+        if constexpr (TWO) { V* r = a; a = b; b = r; return r; }
         __syncthreads();
         return a;
     }
 };
 
 // registers (window AF) -> LDS -> registers (window AT)
-template <int LQ, int AF, int AT, class V>
-__device__ __forceinline__ void exchange(Tiles<V>& tiles, V (&v)[16], uint32_t t, uint32_t q) {
+template <int LQ, int AF, int AT, class V, class TL>
+__device__ __forceinline__ void exchange(TL& tiles, V (&v)[16], uint32_t t, uint32_t q) {
     V* tile = tiles.next();
     V* wp = tile + lds_base<LQ, AF>(t, q);
 #pragma unroll
@@ -175,25 +182,25 @@ __device__ __forceinline__ void exchange(Tiles<V>& tiles, V (&v)[16], uint32_t t
 
 // B-stage DIF of the tile: in: v[j] = point pt_of<B-4>(t, j) (natural order); out: v[j] = position pt_of<0>(t, j),
 // which holds frequency rev_B(position).  twl: stage table in LDS (stages below B-4 at least).
-template <int B, int LQ, class V>
-__device__ __forceinline__ void dif_rounds_after1(V (&v)[16], Tiles<V>& tile, const uint32_t* twl, uint32_t t, uint32_t q) {
+template <int B, int LQ, class V, class TL>
+__device__ __forceinline__ void dif_rounds_after1(V (&v)[16], TL& tile, const uint32_t* twl, uint32_t t, uint32_t q) {
     constexpr int A1 = B - 4, A2 = B > 8 ? B - 8 : 0;
-    exchange<LQ, A1, A2>(tile, v, t, q);
+    exchange<LQ, A1, A2, V>(tile, v, t, q);
     stage_block<A2, A1, A2>(v, twl, t);
     if constexpr (B > 8) {
-        exchange<LQ, A2, 0>(tile, v, t, q);
+        exchange<LQ, A2, 0, V>(tile, v, t, q);
         stage_block<0, A2, 0>(v, twl, t);
     }
 }
-template <int B, int LQ, class V>
-__device__ __forceinline__ void dif_rounds(V (&v)[16], Tiles<V>& tile, const uint32_t (&w1)[15], const uint32_t* twl, uint32_t t, uint32_t q) {
+template <int B, int LQ, class V, class TL>
+__device__ __forceinline__ void dif_rounds(V (&v)[16], TL& tile, const uint32_t (&w1)[15], const uint32_t* twl, uint32_t t, uint32_t q) {
     stage_block_round1(v, w1);
     dif_rounds_after1<B, LQ>(v, tile, twl, t, q);
 }
 // registers in final layout (position pt_of<0>) -> LDS row = frequency rev_B(position) = (rev4(j) << (B-4)) | rev(t)
 // -> registers in the first layout (row pt_of<B-4>): natural frequency order, 16 consecutive rows per 16 lanes.
-template <int B, int LQ, class V>
-__device__ __forceinline__ void to_natural(Tiles<V>& tiles, V (&v)[16], uint32_t t, uint32_t q) {
+template <int B, int LQ, class V, class TL>
+__device__ __forceinline__ void to_natural(TL& tiles, V (&v)[16], uint32_t t, uint32_t q) {
     V* tile = tiles.next();
     const uint32_t rt = rev_bits(t, B - 4);
     V* wp = tile + (((rt + (rt >> 4)) << LQ) + q);
@@ -205,9 +212,9 @@ __device__ __forceinline__ void to_natural(Tiles<V>& tiles, V (&v)[16], uint32_t
     for (uint32_t j = 0; j < 16; j++) v[j] = rp[lds_joff<LQ>(j << (B - 4))];
 }
 // same hand-over without the bit reversal (K3: position order is already the wanted order)
-template <int B, int LQ, class V>
-__device__ __forceinline__ void to_rows(Tiles<V>& tile, V (&v)[16], uint32_t t, uint32_t q) {
-    exchange<LQ, 0, B - 4>(tile, v, t, q);
+template <int B, int LQ, class V, class TL>
+__device__ __forceinline__ void to_rows(TL& tile, V (&v)[16], uint32_t t, uint32_t q) {
+    exchange<LQ, 0, B - 4, V>(tile, v, t, q);
 }
 
 // Adjacent tiles (four of them for 32-byte segments) share 128-byte lines of the strided side: keep them on one XCD (workgroups are dealt to
@@ -249,7 +256,7 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow_inv1_kernel(NarrowAr
     using V = typename Vec<VW>::T;
     constexpr uint32_t NQ = 1u << LQ, NTH = 1u << (B - 4 + LQ);
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    Tiles<V> tile{reinterpret_cast<V*>(smem), reinterpret_cast<V*>(smem)};
+    Tiles<V, false> tile{reinterpret_cast<V*>(smem), reinterpret_cast<V*>(smem)};
     uint32_t* twl = smem + (VW * lds_rows(B) << LQ);                       // stages below B-4: 2^(B-4) - 1 words
     const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> LQ;
     const uint32_t s = tile_of_block<LQ, VW>(blockIdx.x, a.xcd_remap) * NQ + q;  // slot (VW words) within a row group of N2 rows
@@ -275,16 +282,22 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow_inv1_kernel(NarrowAr
 }
 
 // K2: second inverse digit, then per coset: scale, first forward digit, twiddle, strided store.
-template <int B, int LQ, int VW>
-__global__ void __launch_bounds__(1 << (B - 4 + LQ), (B - 4 + LQ >= 9 && NARROW_MID_SHARE_CU) ? 4 : 1) narrow_mid_kernel(NarrowArgs a) {
+// SEQ (column pairs, 512-thread tiles = the 11- and 12-stage digits): the coset transforms run ONE COLUMN AT A TIME
+// on 32-bit registers and two 32-bit LDS tiles that alias the pair tile of the inverse phase; the pair's first
+// result waits in registers for the second and both are stored together.  Meant to fit 128 VGPRs and half the LDS
+// so that two workgroups share a CU; hipcc 7.2 spills instead, so it is compiled out by default (NARROW_MID_SEQ).
+template <int B, int LQ, int VW, bool SEQ>
+__global__ void __launch_bounds__(1 << (B - 4 + LQ), (SEQ ? NARROW_MID_SEQ_WAVES : ((B - 4 + LQ >= 9 && NARROW_MID_SHARE_CU) ? 4 : 1)))
+narrow_mid_kernel(NarrowArgs a) {
     using namespace narrow;
     using V = typename Vec<VW>::T;
+    static_assert(!SEQ || VW == 2, "the column-sequential form is for column pairs");
     constexpr uint32_t NQ = 1u << LQ, NTH = 1u << (B - 4 + LQ);
     constexpr bool LEAN = NTH >= 512;  // at most 256 (1024 threads: 128) VGPRs per lane: rebuild the output ladder per coset
-    constexpr uint32_t NT = NTH >= 1024 ? 1 : NARROW_MID_TILES;
+    constexpr uint32_t NT = (SEQ || NTH >= 1024) ? 1 : NARROW_MID_TILES;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // two tiles (one barrier per hand-over): the 15 hand-overs of a blowup-4 middle pass are this kernel's stalls
-    Tiles<V> tile{reinterpret_cast<V*>(smem), reinterpret_cast<V*>(smem) + (NT - 1) * (lds_rows(B) << LQ)};
+    Tiles<V, (NT > 1)> tile{reinterpret_cast<V*>(smem), reinterpret_cast<V*>(smem) + (NT - 1) * (lds_rows(B) << LQ)};
     uint32_t* twl_i = smem + (NT * VW * lds_rows(B) << LQ);   // inverse stages below B-4
     uint32_t* twl_f = twl_i + (1u << (B - 4));                // forward stages below B-4
     const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> LQ;
@@ -308,27 +321,65 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ), (B - 4 + LQ >= 9 && NARROW_
     const uint64_t kbase = (uint64_t)k1 + ((uint64_t)t << a.n1);
     uint32_t sc_next = two_level(a.sc_lo[0], a.sc_hi[0], a.sc_T, kbase);
     to_natural<B, LQ>(tile, c, t, q);  // c[j] = coefficient k = k1 + N1 * k2, k2 = pt_of<B-4>(t, j) = (j << (B-4)) | t
-    uint32_t pw2[16];
-    if constexpr (!LEAN) power_ladder<16>(c0, phi0, pw2);
     const uint32_t ncos = 1u << a.added;
-    for (uint32_t jc = 0; jc < ncos; jc++) {
-        const uint32_t sc = sc_next;
-        if (jc + 1 < ncos) sc_next = two_level(a.sc_lo[jc + 1], a.sc_hi[jc + 1], a.sc_T, kbase);
-        uint32_t w1[15];  // in flight while the scale ladder runs
-        load_round1_twiddles<B>(a.stage_tw_fwd, t, w1);
-        V v[16];
+    if constexpr (SEQ) {
+        __syncthreads();  // the 32-bit tiles below alias the pair tile: its last reads (to_natural) are done
+        Tiles<uint32_t, true> t32{smem, smem + (lds_rows(B) << LQ)};
+        for (uint32_t jc = 0; jc < ncos; jc++) {
+            const uint32_t sc = sc_next;
+            if (jc + 1 < ncos) sc_next = two_level(a.sc_lo[jc + 1], a.sc_hi[jc + 1], a.sc_T, kbase);
+            // per column: round-1 twiddles and the scale ladder are rebuilt (15 loads + 18 products) rather than kept
+            // live across both columns — the 128-VGPR budget holds c (32), the first column's result (16) and v (16)
+            uint32_t r0[16], v[16];
+            {
+                uint32_t w1[15], pw[16];
+                load_round1_twiddles<B>(a.stage_tw_fwd, t, w1);
+                power_ladder<16>(sc, a.sc_phi[jc], pw);
 #pragma unroll
-        for (uint32_t j = 0; j < 16; j++) v[j] = c[j];
-        scale_ladder<false>(v, sc, a.sc_phi[jc]);
-        dif_rounds<B, LQ>(v, tile, w1, twl_f, t, q);
-        uint32_t* o = a.dst + ((uint64_t)rev_bits(jc, a.added) << a.n) * a.W;  // position (t << 4) | j of the coset's block
-        if constexpr (LEAN) {
-            scale_ladder<true>(v, c0, phi0);
+                for (uint32_t j = 0; j < 16; j++) v[j] = bb::mul(c[j].x, pw[j]);
+                dif_rounds<B, LQ>(v, t32, w1, twl_f, t, q);
+            }
 #pragma unroll
-            for (uint32_t j = 0; j < 16; j++) stv<V>(o + (uint64_t)j * rowstride, st_off, v[j]);
-        } else {
+            for (uint32_t j = 0; j < 16; j++) r0[j] = v[j];
+            {
+                uint32_t w1[15], pw[16];
+                load_round1_twiddles<B>(a.stage_tw_fwd, t, w1);
+                power_ladder<16>(sc, a.sc_phi[jc], pw);
 #pragma unroll
-            for (uint32_t j = 0; j < 16; j++) stv<V>(o + (uint64_t)j * rowstride, st_off, mul2(v[j], pw2[crev(j, 4)]));
+                for (uint32_t j = 0; j < 16; j++) v[j] = bb::mul(c[j].y, pw[j]);
+                dif_rounds<B, LQ>(v, t32, w1, twl_f, t, q);
+            }
+            uint32_t pw[16];
+            uint32_t* o = a.dst + ((uint64_t)rev_bits(jc, a.added) << a.n) * a.W;
+            power_ladder<16>(c0, phi0, pw);
+#pragma unroll
+            for (uint32_t j = 0; j < 16; j++) {
+                const uint32_t wj = pw[crev(j, 4)];
+                stv<V>(o + (uint64_t)j * rowstride, st_off, make_uint2(bb::mul(r0[j], wj), bb::mul(v[j], wj)));
+            }
+        }
+    } else {
+        uint32_t pw2[16];
+        if constexpr (!LEAN) power_ladder<16>(c0, phi0, pw2);
+        for (uint32_t jc = 0; jc < ncos; jc++) {
+            const uint32_t sc = sc_next;
+            if (jc + 1 < ncos) sc_next = two_level(a.sc_lo[jc + 1], a.sc_hi[jc + 1], a.sc_T, kbase);
+            uint32_t w1[15];  // in flight while the scale ladder runs
+            load_round1_twiddles<B>(a.stage_tw_fwd, t, w1);
+            V v[16];
+#pragma unroll
+            for (uint32_t j = 0; j < 16; j++) v[j] = c[j];
+            scale_ladder<false>(v, sc, a.sc_phi[jc]);
+            dif_rounds<B, LQ>(v, tile, w1, twl_f, t, q);
+            uint32_t* o = a.dst + ((uint64_t)rev_bits(jc, a.added) << a.n) * a.W;  // position (t << 4) | j of the coset's block
+            if constexpr (LEAN) {
+                scale_ladder<true>(v, c0, phi0);
+#pragma unroll
+                for (uint32_t j = 0; j < 16; j++) stv<V>(o + (uint64_t)j * rowstride, st_off, v[j]);
+            } else {
+#pragma unroll
+                for (uint32_t j = 0; j < 16; j++) stv<V>(o + (uint64_t)j * rowstride, st_off, mul2(v[j], pw2[crev(j, 4)]));
+            }
         }
     }
 }
@@ -340,7 +391,7 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow_fwd2_kernel(NarrowAr
     using V = typename Vec<VW>::T;
     constexpr uint32_t NQ = 1u << LQ, NTH = 1u << (B - 4 + LQ);
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    Tiles<V> tile{reinterpret_cast<V*>(smem), reinterpret_cast<V*>(smem)};
+    Tiles<V, false> tile{reinterpret_cast<V*>(smem), reinterpret_cast<V*>(smem)};
     uint32_t* twl = smem + (VW * lds_rows(B) << LQ);
     const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> LQ;
     const uint32_t s = blockIdx.x * NQ + q;

@@ -5,7 +5,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libp3hip.so")
+LIB_PATH = os.environ.get("P3HIP_LIB") or os.path.join(_HERE, "libp3hip.so")  # P3HIP_LIB: experiment builds
 ROOT = os.path.dirname(_HERE)
 
 u32p = C.POINTER(C.c_uint32)

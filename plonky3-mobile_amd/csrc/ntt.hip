@@ -887,6 +887,11 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     if (rc) return rc;
     uint32_t* T = cx.ws[1].as<uint32_t>();
     NarrowArgs a{};
+    static int use_blocked = [] { const char* e = getenv("P3HIP_NTT_NARROW_BLOCKED"); return e ? atoi(e) : 1; }();
+    static int use_handover = [] { const char* e = getenv("P3HIP_NTT_NARROW_HANDOVER"); return e ? atoi(e) : 0; }();
+    // blocked intermediates need tiles of 4 rows in all three kernels (32-byte tile rows: digits below 12 stages)
+    a.blocked = use_blocked && !NARROW_MID_SEQ && W == 2 && n1 < 12 && n2 < 12;
+    a.mid_handover = use_handover;
     a.n = n; a.n1 = n1; a.n2 = n2; a.W = W; a.added = added;
     TwoLevelTable ti, tf;
     if ((rc = cx.get_root_table(n, true, &ti))) return rc;

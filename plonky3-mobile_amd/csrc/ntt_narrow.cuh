@@ -30,9 +30,15 @@
 #ifndef NARROW_MID_TILES
 #define NARROW_MID_TILES 2  // LDS tiles of the middle kernel (1 or 2)
 #endif
+#ifndef NARROW_SKIP
+#define NARROW_SKIP 0  // experiment builds only: 1 = no butterflies / ladders (the load, LDS and store skeleton alone)
+#endif
 #ifndef NARROW_MID_SEQ
 #define NARROW_MID_SEQ 0  // experiment: column-sequential coset loop for the 512-thread pair tiles (measured 2x SLOWER:
                           // the compiler spills ~85 registers at the 128-VGPR cap; 2^24 middle pass 549 -> 1063 us)
+#endif
+#ifndef NARROW_SKIP
+#define NARROW_SKIP 0  // experiment builds only: 1 = no butterflies / ladders (the load, LDS and store skeleton alone)
 #endif
 #ifndef NARROW_MID_SEQ_WAVES
 #define NARROW_MID_SEQ_WAVES 4
@@ -60,6 +66,10 @@ struct NarrowArgs {
     uint32_t sc_T;
     uint32_t sc_phi[8];           // (shift g^j)^(N1 * 2^(n2-4))
     uint32_t xcd_remap;           // 1: tile count is a multiple of 32, spread groups of 4 adjacent tiles per XCD
+    uint32_t mid_handover;        // blocked: the middle kernel re-sorts its results through LDS to store whole lines
+    uint32_t blocked;             // W = 2: the two intermediates are stored in 128-byte blocks of
+                                  // 4 x 4 (row of one digit, row of the other) pairs, so that the kernel that reads
+                                  // them strided touches whole cache lines instead of 32-byte segments
 };
 
 namespace narrow {
@@ -106,6 +116,7 @@ constexpr uint32_t lds_rows(int B) { return (1u << B) + (1u << (B - 4)); }
 // (a, b) -> (a + b, (a - b) * w_{2^(u+1)}^(pt mod 2^u))   [stage semantics of backend_vulkan.rs:881-942, DIF form]
 template <int A, int UHI, int ULO, class V>
 __device__ __forceinline__ void stage_block(V (&v)[16], const uint32_t* __restrict__ tw, uint32_t t) {
+    if (NARROW_SKIP) return;
     const uint32_t tlo = t & ((1u << A) - 1u);
 #pragma unroll
     for (int u = UHI - 1; u >= ULO; --u) {
@@ -139,6 +150,7 @@ __device__ __forceinline__ void load_round1_twiddles(const uint32_t* __restrict_
 }
 template <class V>
 __device__ __forceinline__ void stage_block_round1(V (&v)[16], const uint32_t (&w1)[15]) {
+    if (NARROW_SKIP) { v[0] = add2(v[0], mul2(v[1], w1[0] & 1u)); return; }  // keep the twiddle loads alive
 #pragma unroll
     for (int d = 3; d >= 0; --d) {
 #pragma unroll
@@ -241,6 +253,7 @@ __device__ __forceinline__ void stv(void* base, uint32_t off, V v) {
 // v[j] *= c * phi^(idx(j)), idx(j) = REV ? rev4(j) : j
 template <bool REV, class V>
 __device__ __forceinline__ void scale_ladder(V (&v)[16], uint32_t c, uint32_t phi) {
+    if (NARROW_SKIP) { v[0] = add2(v[0], mul2(v[1], (c ^ phi) & 1u)); return; }
     uint32_t pw[16];
     power_ladder<16>(c, phi, pw);
 #pragma unroll
@@ -276,6 +289,14 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow_inv1_kernel(NarrowAr
     scale_ladder<true>(v, c, phi);
     to_natural<B, LQ>(tile, v, t, q);
     // T[(lo * N1 + k1) * W + VW cp], k1 = pt_of<B-4>(t, j): consecutive lanes (cp, then k1) are contiguous for W <= NQ * VW
+    if (a.blocked) {
+        // W = 2: block (r2 >> 2, k1 >> 2) of 128 bytes holds the row pairs (r2 & 3, k1 & 3), 8 bytes each (cp = column
+        // for single-column lanes); this tile is the r2 group lo >> 2
+        const uint32_t blk_off = ((((lo >> 2) << (B - 2)) + (t >> 2)) * 16u + (lo & 3u) * 4u + (t & 3u)) * 8u + cp * 4u;
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) stv<V>(a.dst + ((uint64_t)j << (B - 6)) * 32u, blk_off, v[j]);
+        return;
+    }
     const uint32_t st_off = (((lo << B) + t) * a.W + VW * cp) * 4u;
 #pragma unroll
     for (uint32_t j = 0; j < 16; j++) stv<V>(a.dst + ((uint64_t)j << (B - 4)) * a.W, st_off, v[j]);
@@ -305,9 +326,15 @@ narrow_mid_kernel(NarrowArgs a) {
     const uint32_t k1 = s >> a.wsl;
     const uint32_t rowstride = a.W << a.n1;
     const uint32_t ld_off = (VW * s + t * rowstride) * 4u, st_off = (VW * s + (t << 4) * rowstride) * 4u;
+    const bool blocked = a.blocked;
+    // blocked (W = 2): pair (row r, k1) sits in block (r >> 2, k1 >> 2) at (r & 3) * 4 + (k1 & 3); this tile is one k1 group
+    const uint32_t blk_off = ((((t >> 2) << (a.n1 - 2)) + (k1 >> 2)) * 16u + (t & 3u) * 4u + (k1 & 3u)) * 8u +
+                             (VW == 1 ? (s & 1u) * 4u : 0u);
+    const uint64_t blk_jstride = ((uint64_t)32u << (B - 6)) << (a.n1 - 2);  // words between rows j << (B-4) apart
     V c[16];
 #pragma unroll
-    for (uint32_t j = 0; j < 16; j++) c[j] = ldv<V>(a.src + ((uint64_t)j << (B - 4)) * rowstride, ld_off);
+    for (uint32_t j = 0; j < 16; j++)
+        c[j] = blocked ? ldv<V>(a.src + (uint64_t)j * blk_jstride, blk_off) : ldv<V>(a.src + ((uint64_t)j << (B - 4)) * rowstride, ld_off);
     {
         uint32_t w1[15];
         load_round1_twiddles<B>(a.stage_tw, t, w1);
@@ -372,6 +399,28 @@ narrow_mid_kernel(NarrowArgs a) {
             scale_ladder<false>(v, sc, a.sc_phi[jc]);
             dif_rounds<B, LQ>(v, tile, w1, twl_f, t, q);
             uint32_t* o = a.dst + ((uint64_t)rev_bits(jc, a.added) << a.n) * a.W;  // position (t << 4) | j of the coset's block
+            if (blocked && !a.mid_handover) {
+                // blocked positions straight from the final layout: position (t << 4) | j -> block ((t << 2) | (j >> 2), k1 group)
+                const uint32_t fin_off = (((t << 2) << (a.n1 - 2)) + (k1 >> 2)) * 128u + (k1 & 3u) * 8u + (VW == 1 ? (s & 1u) * 4u : 0u);
+                uint32_t pwl[16];
+                if constexpr (LEAN) power_ladder<16>(c0, phi0, pwl);
+#pragma unroll
+                for (uint32_t j = 0; j < 16; j++)
+                    stv<V>(o + ((uint64_t)(j >> 2) << (a.n1 - 2)) * 32u, fin_off + (j & 3u) * 32u, mul2(v[j], LEAN ? pwl[crev(j, 4)] : pw2[crev(j, 4)]));
+                continue;
+            }
+            if (blocked) {
+                // twiddle, then one more hand-over so that 16 consecutive lanes hold 16 consecutive rows: whole lines
+                if constexpr (LEAN) scale_ladder<true>(v, c0, phi0);
+                else {
+#pragma unroll
+                    for (uint32_t j = 0; j < 16; j++) v[j] = mul2(v[j], pw2[crev(j, 4)]);
+                }
+                to_rows<B, LQ>(tile, v, t, q);
+#pragma unroll
+                for (uint32_t j = 0; j < 16; j++) stv<V>(o + (uint64_t)j * blk_jstride, blk_off, v[j]);
+                continue;
+            }
             if constexpr (LEAN) {
                 scale_ladder<true>(v, c0, phi0);
 #pragma unroll
@@ -399,8 +448,15 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow_fwd2_kernel(NarrowAr
     uint32_t* p = a.dst + ((uint64_t)blk0 << B) * a.W;                    // uniform: the workgroup's first block
     const uint32_t off = ((((blk - blk0) << B) + t) * a.W + VW * cp) * 4u;
     V v[16];
+    if (a.blocked) {
+        // W = 2: the workgroup's four blocks of 2^B rows arrive as 128-byte blocks (k1 >> 2) of pairs (row block & 3, k1 & 3)
+        const uint32_t blk_off = ((t >> 2) * 16u + (blk - blk0) * 4u + (t & 3u)) * 8u + cp * 4u;
 #pragma unroll
-    for (uint32_t j = 0; j < 16; j++) v[j] = ldv<V>(p + ((uint64_t)j << (B - 4)) * a.W, off);
+        for (uint32_t j = 0; j < 16; j++) v[j] = ldv<V>(p + ((uint64_t)j << (B - 6)) * 32u, blk_off);
+    } else {
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) v[j] = ldv<V>(p + ((uint64_t)j << (B - 4)) * a.W, off);
+    }
     uint32_t w1[15];
     load_round1_twiddles<B>(a.stage_tw, t, w1);
     for (uint32_t i = threadIdx.x; i + 1 < (1u << (B - 4)); i += NTH) twl[i] = a.stage_tw[i];

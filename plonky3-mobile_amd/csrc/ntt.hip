@@ -827,7 +827,7 @@ int launch_narrow_t(hipStream_t stream, const NarrowArgs& a, uint32_t blocks) {
     constexpr size_t tile_bytes = ((size_t)4 * VW * narrow::lds_rows(B)) << LQ;
     // the middle kernel of 512-thread pair tiles runs column-sequentially (one pair tile, two workgroups per CU)
     constexpr bool SEQ = K == 2 && VW == 2 && B - 4 + LQ == 9 && NARROW_MID_SEQ;
-    constexpr size_t n_tiles = K == 2 ? ((SEQ || B - 4 + LQ >= 10) ? 1 : NARROW_MID_TILES) : 1;
+    constexpr size_t n_tiles = K == 2 ? ((SEQ || B - 4 + LQ >= 10) ? 1 : NARROW_MID_TILES) : (B >= 11 ? 1 : NARROW_EDGE_TILES);
     constexpr size_t lds = tile_bytes * n_tiles + ((size_t)4 << (B - 4)) * (K == 2 ? 2 : 1);
     static_assert(lds <= 160 * 1024, "narrow tile does not fit the LDS");
     void (*kern)(NarrowArgs);

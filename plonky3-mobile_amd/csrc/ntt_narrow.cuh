@@ -27,6 +27,9 @@
 // Experiment switch: compile the 512-thread middle kernels for 4 waves per SIMD (128 VGPRs) so that two workgroups
 // share a CU.  Measured slower (the 2^24 middle pass 586 -> 898 us): the ~55 spilled registers cost more than the
 // second workgroup hides.
+#ifndef NARROW_EDGE_TILES
+#define NARROW_EDGE_TILES 2  // LDS tiles of the first and last kernel for digits below 11 stages (1 or 2; two cost a workgroup per CU from 11 stages on)
+#endif
 #ifndef NARROW_MID_TILES
 #define NARROW_MID_TILES 2  // LDS tiles of the middle kernel (1 or 2)
 #endif
@@ -269,8 +272,9 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow_inv1_kernel(NarrowAr
     using V = typename Vec<VW>::T;
     constexpr uint32_t NQ = 1u << LQ, NTH = 1u << (B - 4 + LQ);
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    Tiles<V, false> tile{reinterpret_cast<V*>(smem), reinterpret_cast<V*>(smem)};
-    uint32_t* twl = smem + (VW * lds_rows(B) << LQ);                       // stages below B-4: 2^(B-4) - 1 words
+    constexpr uint32_t NT = B >= 11 ? 1 : NARROW_EDGE_TILES;              // two tiles: one barrier per hand-over
+    Tiles<V, (NT > 1)> tile{reinterpret_cast<V*>(smem), reinterpret_cast<V*>(smem) + (NT - 1) * (lds_rows(B) << LQ)};
+    uint32_t* twl = smem + (NT * VW * lds_rows(B) << LQ);                  // stages below B-4: 2^(B-4) - 1 words
     const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> LQ;
     const uint32_t s = tile_of_block<LQ, VW>(blockIdx.x, a.xcd_remap) * NQ + q;  // slot (VW words) within a row group of N2 rows
     const uint32_t lo = s >> a.wsl, cp = s & ((1u << a.wsl) - 1u);
@@ -440,8 +444,9 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow_fwd2_kernel(NarrowAr
     using V = typename Vec<VW>::T;
     constexpr uint32_t NQ = 1u << LQ, NTH = 1u << (B - 4 + LQ);
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    Tiles<V, false> tile{reinterpret_cast<V*>(smem), reinterpret_cast<V*>(smem)};
-    uint32_t* twl = smem + (VW * lds_rows(B) << LQ);
+    constexpr uint32_t NT = B >= 11 ? 1 : NARROW_EDGE_TILES;
+    Tiles<V, (NT > 1)> tile{reinterpret_cast<V*>(smem), reinterpret_cast<V*>(smem) + (NT - 1) * (lds_rows(B) << LQ)};
+    uint32_t* twl = smem + (NT * VW * lds_rows(B) << LQ);
     const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> LQ;
     const uint32_t s = blockIdx.x * NQ + q;
     const uint32_t blk0 = (blockIdx.x * NQ) >> a.wsl, blk = s >> a.wsl, cp = s & ((1u << a.wsl) - 1u);

@@ -202,12 +202,19 @@ def main():
                           "peak": 7.26, "unit": "Gperm/s", "instructions_per_permutation": 5156,
                           "peak_basis": "5.16k wave-instructions per permutation (ISA count of compress_layer_f64_kernel), "
                                         "nearly all fp64 VALU at 4.2 cycles each, on 1024 SIMDs at 2.4 GHz "
-                                        "(profiles/r01_microbench2_valu_issue_rates.txt)"},
+                                        "(profiles/r01_microbench2_valu_issue_rates.txt)",
+                          # sustained: tools/clock_probe.hip (profiles/r01_v5_clock_probe_sustained_valu.txt) — under a
+                          # chip-wide fp64 FMA load the shader clock settles at ~1.93 GHz and a SIMD retires one fp64
+                          # wave-instruction per 4.55 of those cycles: 434 G wave-instructions/s chip-wide
+                          "sustained_peak": 434.0e9 / 4850 * 64 / 1e9,
+                          "sustained_basis": "434 G fp64 wave-instructions/s measured chip-wide under sustained load "
+                                             "(1.93 GHz x 1024 SIMDs / 4.55 cycles) / 4.85k VALU instructions per permutation"},
         "stages_ms": job.stage_breakdown(),
         "collectives": coll_state["mode"],
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["valu_roofline"]["frac"] = out["valu_roofline"]["achieved"] / out["valu_roofline"]["peak"]
+        out["valu_roofline"]["frac_of_sustained"] = out["valu_roofline"]["achieved"] / out["valu_roofline"]["sustained_peak"]
         out["cpu_baseline"] = cpu_baseline(args.log_height, args.log_blowup, job, 1 if args.hash == "keccak" else 0)
     job.close()
     if rank == 0:

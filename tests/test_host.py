@@ -126,3 +126,16 @@ def test_plan_helpers_mirror_reference_layouts(p3, oracle):
     assert np.array_equal(pl.write_bit_reversed_rows_u32(x.reshape(-1), 3).reshape(64, 3), oracle.bit_reverse_rows(x))
     assert np.array_equal(pl.write_bit_reversed_rows_u32(x[:24].reshape(-1), 3), x[:24].reshape(-1))  # 24 rows: copied
     assert [pl.reverse_bits_len(i, 3) for i in range(8)] == [0, 4, 2, 6, 1, 5, 3, 7]
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/p3hip.h is the drop-in boundary: it must compile as C11 (no C++, no torch, no HIP types)."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "p3hip.h"\nint main(void) { return p3hip_get_backend() < -100; }\n')
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        "-fsyntax-only", str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

@@ -21,6 +21,7 @@
 #include "keccak.cuh"
 #include "mmcs.h"
 #include "poseidon2.cuh"
+#include "poseidon2_f64.cuh"
 #include "prover.h"
 
 namespace p3 {
@@ -272,14 +273,14 @@ __global__ void __launch_bounds__(256) grind_kernel(const uint32_t* state16, uin
                                                     uint32_t* result) {
     uint32_t w = base + blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= bb::P) return;
-    uint32_t s[16];
+    // fp64 form of the permutation (poseidon2_f64.cuh: canonical values in doubles), as in the tree kernels
+    double s[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) s[i] = state16[i];
-    uint32_t wm = bb::to_monty(w);
+    for (int i = 0; i < 16; i++) s[i] = p2f::load_elem(state16[i]);
 #pragma unroll
-    for (int i = 0; i < 8; i++) s[i] = (i == (int)pos) ? wm : s[i];
-    p2::permute(s);
-    if ((bb::from_monty(s[7]) & mask) == 0) atomicMin(result, w);
+    for (int i = 0; i < 8; i++) s[i] = (i == (int)pos) ? (double)w : s[i];
+    p2f::permute(s);
+    if ((bb::from_monty(p2f::store_elem(s[7])) & mask) == 0) atomicMin(result, w);
 }
 
 // The same search for the Keccak-256 HashChallenger: candidate w is observed as the 4 little-endian bytes of its

@@ -179,6 +179,9 @@ int p3hip_verify_fib_air_hash(int hash, const uint8_t *proof, size_t len, uint64
 typedef struct p3hip_fib_batch p3hip_fib_batch_t;
 int p3hip_fib_batch_create(unsigned log_n, const p3hip_fri_params_t *params, unsigned n_provers,
                            p3hip_fib_batch_t **out);
+/* the pool under either hash configuration (P3HIP_HASH_POSEIDON2 / P3HIP_HASH_KECCAK) */
+int p3hip_fib_batch_create_hash(int hash, unsigned log_n, const p3hip_fri_params_t *params, unsigned n_provers,
+                                p3hip_fib_batch_t **out);
 int p3hip_fib_batch_prove(p3hip_fib_batch_t *batch, size_t n, const uint64_t *a, const uint64_t *b,
                           const uint8_t **proofs_out, size_t *lens_out);
 void p3hip_fib_batch_destroy(p3hip_fib_batch_t *batch);

@@ -157,9 +157,10 @@ struct FriParameters {  // p3_fri::FriParameters; defaults = create_benchmark_fr
 };
 class FibAirProver {  // prove(&config, &FibonacciAir{}, generate_trace_rows(a, b, n), &pis), fib_air.rs:61-70
   public:
-    FibAirProver(unsigned log_n, FriParameters fp = FriParameters()) {
+    // hash: P3HIP_HASH_POSEIDON2 (north_star) or P3HIP_HASH_KECCAK (the reference's own hashes, fib_air.rs:28-53)
+    FibAirProver(unsigned log_n, FriParameters fp = FriParameters(), int hash = P3HIP_HASH_POSEIDON2) {
         p3hip_fri_params_t c{fp.log_blowup, fp.log_final_poly_len, fp.num_queries, fp.proof_of_work_bits};
-        check(p3hip_fib_prover_create(log_n, &c, nullptr, 1, &h_));
+        check(p3hip_fib_prover_create_hash(hash, log_n, &c, nullptr, 1, &h_));
     }
     FibAirProver(const FibAirProver&) = delete;
     ~FibAirProver() { if (h_) p3hip_fib_prover_destroy(h_); }
@@ -177,9 +178,9 @@ class FibAirProver {  // prove(&config, &FibonacciAir{}, generate_trace_rows(a, 
 // A pool of provers (one host thread + stream each) for batches of independent instances (BASELINE configs[3]).
 class FibAirBatchProver {
   public:
-    FibAirBatchProver(unsigned log_n, unsigned n_provers = 8, FriParameters fp = FriParameters()) {
+    FibAirBatchProver(unsigned log_n, unsigned n_provers = 8, FriParameters fp = FriParameters(), int hash = P3HIP_HASH_POSEIDON2) {
         p3hip_fri_params_t c{fp.log_blowup, fp.log_final_poly_len, fp.num_queries, fp.proof_of_work_bits};
-        check(p3hip_fib_batch_create(log_n, &c, n_provers, &h_));
+        check(p3hip_fib_batch_create_hash(hash, log_n, &c, n_provers, &h_));
     }
     FibAirBatchProver(const FibAirBatchProver&) = delete;
     ~FibAirBatchProver() { if (h_) p3hip_fib_batch_destroy(h_); }
@@ -207,15 +208,16 @@ inline uint64_t fib_public_x(uint64_t a, uint64_t b, uint64_t n) {
 }
 // verify(&config, &FibonacciAir{}, &proof, &pis) (fib_air.rs:71-72); throws Error("fib_air verification failed: ...")
 inline void verify_fib_air(const std::vector<uint8_t>& proof, uint64_t a, uint64_t b, uint64_t x, unsigned log_n,
-                           FriParameters fp = FriParameters()) {
+                           FriParameters fp = FriParameters(), int hash = P3HIP_HASH_POSEIDON2) {
     p3hip_fri_params_t c{fp.log_blowup, fp.log_final_poly_len, fp.num_queries, fp.proof_of_work_bits};
-    check(p3hip_verify_fib_air(proof.data(), proof.size(), a, b, x, log_n, &c));
+    check(p3hip_verify_fib_air_hash(hash, proof.data(), proof.size(), a, b, x, log_n, &c));
 }
-// run_fib_air_zk (fib_air.rs:27-75) on the hip backend, Poseidon2 configuration: "fib_air ok (n=8, x=21)"
-inline std::string run_fib_air(unsigned log_n = 3, uint64_t a = 0, uint64_t b = 1, FriParameters fp = FriParameters()) {
+// run_fib_air_zk (fib_air.rs:27-75) on the hip backend (non-hiding; either hash configuration): "fib_air ok (n=8, x=21)"
+inline std::string run_fib_air(unsigned log_n = 3, uint64_t a = 0, uint64_t b = 1, FriParameters fp = FriParameters(),
+                               int hash = P3HIP_HASH_POSEIDON2) {
     uint64_t n = 1ull << log_n, x = fib_public_x(a, b, n);
-    FibAirProver prover(log_n, fp);
-    verify_fib_air(prover.prove(a, b), a, b, x, log_n, fp);
+    FibAirProver prover(log_n, fp, hash);
+    verify_fib_air(prover.prove(a, b), a, b, x, log_n, fp, hash);
     return "fib_air ok (n=" + std::to_string(n) + ", x=" + std::to_string(x) + ")";
 }
 

@@ -421,6 +421,7 @@ int p3hip_verify_fib_air_hash(int hash, const uint8_t* proof, size_t len, uint64
 // ---- batches of independent proofs (BASELINE configs[3]): a pool of provers, one host thread + stream each ----
 struct p3hip_fib_batch {
     unsigned log_n = 0;
+    int hash = HASH_POSEIDON2;
     FriParams fp{};
     std::vector<std::thread> workers;
     std::mutex mu;
@@ -440,7 +441,7 @@ struct p3hip_fib_batch {
         hipStream_t st = nullptr;
         int rc = get_context_status();
         if (rc == OK && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) rc = fail(ERR_HIP, "hipStreamCreateWithFlags failed");
-        if (rc == OK) rc = prover.init(log_n, fp, st, true);
+        if (rc == OK) rc = prover.init(log_n, fp, st, true, hash);
         {
             std::unique_lock<std::mutex> lk(mu);
             if (rc != OK && first_error == 0) { first_error = rc; std::string t; take_error(&t); error_text = t; }
@@ -474,10 +475,16 @@ struct p3hip_fib_batch {
 extern "C" {
 
 int p3hip_fib_batch_create(unsigned log_n, const p3hip_fri_params_t* params, unsigned n_provers, p3hip_fib_batch_t** out) {
+    return p3hip_fib_batch_create_hash(HASH_POSEIDON2, log_n, params, n_provers, out);
+}
+int p3hip_fib_batch_create_hash(int hash, unsigned log_n, const p3hip_fri_params_t* params, unsigned n_provers,
+                                p3hip_fib_batch_t** out) {
     return guarded([&]() -> int {
         if (!params || !out || n_provers == 0 || n_provers > 64) return fail(ERR_BAD_ARG, "fib_batch_create: bad argument");
+        if (hash != HASH_POSEIDON2 && hash != HASH_KECCAK) return fail(ERR_BAD_ARG, "fib_batch_create: unknown hash configuration");
         std::unique_ptr<p3hip_fib_batch> bt(new p3hip_fib_batch());
         bt->log_n = log_n;
+        bt->hash = hash;
         bt->fp = FriParams{params->log_blowup, params->log_final_poly_len, params->num_queries, params->proof_of_work_bits};
         for (unsigned t = 0; t < n_provers; t++) bt->workers.emplace_back([p = bt.get()] { p->worker_main(); });
         {

@@ -103,3 +103,15 @@ def test_keccak_config_headline_size(p3, oracle):
     x = oracle.fib_public_x(0, 1, 1 << 20)
     assert oracle.verify_fib_air(proof, 0, 1, x, 20, oracle.FriParams(), hash=oracle.HASH_KECCAK) == 0
     assert p3.run_fib_air(hash="keccak") == "fib_air ok (n=8, x=21)"
+
+
+def test_keccak_batch_pool(p3, oracle):
+    pool = p3.FibAirBatchProver(10, n_provers=3, params=p3.FriParameters(1, 0, 10, 6), hash="keccak")
+    try:
+        inst = [(i, i + 1) for i in range(7)]
+        proofs = pool.prove(inst)
+        ofp = oracle.FriParams(1, 0, 10, 6)
+        for (a, b), pf in zip(inst, proofs):
+            assert pf == oracle.prove_fib_air(a, b, 10, ofp, hash=oracle.HASH_KECCAK)
+    finally:
+        pool.close()

@@ -61,6 +61,8 @@ int main(int argc, char** argv) {
         std::string rep = run_fib_air();  // the reference's instance: n = 8, x = 21 (fib_air.rs:56-57)
         std::printf("%s\n", rep.c_str());
         if (rep != "fib_air ok (n=8, x=21)") { std::printf("FAIL run_fib_air\n"); return 7; }
+        // the same instance under the reference's own hashes (Keccak MMCS + Keccak-256 hash challenger)
+        if (run_fib_air(3, 0, 1, FriParameters(), P3HIP_HASH_KECCAK) != rep) { std::printf("FAIL run_fib_air keccak\n"); return 11; }
         try { verify_fib_air(proof, 0, 1, 5, argc > 1 ? std::atoi(argv[1]) : 12); std::printf("FAIL verify accepted a wrong x\n"); return 8; }
         catch (const Error& e) { std::printf("expected error: %s\n", e.what()); }
         {   // batch of independent proofs through the library's prover pool

@@ -184,7 +184,7 @@ def main():
         "dtype": "u32 (BabyBear Montgomery, 31-bit modular)",
         "data": "synthetic",
         "config": {"workload": job.workload_name(), "log_height": args.log_height, "width": 2,
-                   "log_blowup": args.log_blowup, "batch_per_gpu": args.batch,
+                   "log_blowup": args.log_blowup, "hash": args.hash, "batch_per_gpu": args.batch,
                    "concurrent_provers_per_gpu": job.threads,
                    "fri": {"log_final_poly_len": job.params.log_final_poly_len, "num_queries": job.params.num_queries,
                            "proof_of_work_bits": job.params.proof_of_work_bits},

@@ -359,6 +359,41 @@ __global__ void __launch_bounds__(256) keccak_compress_kernel(const uint32_t* pr
     }
     store_digest64(next + i * 8, st);
 }
+// Finishes a Keccak tree whose current layer has at most 2048 digests: all remaining (injection-free) levels in ONE
+// workgroup, the current layer mirrored in LDS.  A level costs one permutation latency either way (~13 us: the 64-bit
+// lanes have no 16-lane cooperative form), but eleven launches become one — the small layers of the ~22 trees of a
+// proof were ~350 of its ~450 launches.  layer0: consecutive layers in HBM, n0 digests followed by n0/2, ...
+__global__ void __launch_bounds__(1024) keccak_tree_top_kernel(uint32_t* layer0, uint32_t n0, uint32_t* root_copy) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < n0 * 2; i += blockDim.x)
+        reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(layer0)[i];
+    __syncthreads();
+    uint32_t* out = layer0 + (size_t)n0 * 8;
+    for (uint32_t n = n0; n > 1; n >>= 1) {
+        const uint32_t half = n >> 1;
+        uint64_t st[25];
+        const bool act = tid < half;
+        if (act) {
+            const uint64_t* p = reinterpret_cast<const uint64_t*>(lds) + (size_t)tid * 8;
+#pragma unroll
+            for (int k = 0; k < 8; k++) st[k] = p[k];
+#pragma unroll
+            for (int k = 8; k < 25; k++) st[k] = 0;
+            kk::permute(st);
+        }
+        __syncthreads();
+        if (act) {
+            uint64_t* p = reinterpret_cast<uint64_t*>(lds) + (size_t)tid * 4;
+#pragma unroll
+            for (int k = 0; k < 4; k++) p[k] = st[k];
+            store_digest64(out + (size_t)tid * 8, st);
+            if (half == 1 && root_copy) store_digest64(root_copy, st);
+        }
+        __syncthreads();
+        out += (size_t)half * 8;
+    }
+}
 __global__ void keccak_f_kernel(uint64_t* states, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -477,6 +512,18 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
         for (size_t l = 1; l < t->layer_len.size(); l++) {
             uint64_t len = t->layer_len[l];
             RowSet rs = make_rowset(*t, len);
+            if (len <= 1024) {  // the rest of the tree in one workgroup when no shorter matrix is injected any more
+                bool clean = true;
+                for (size_t k = l; k < t->layer_len.size(); k++) clean = clean && !has_height(*t, t->layer_len[k]);
+                if (clean) {
+                    const uint32_t n0 = (uint32_t)t->layer_len[l - 1];
+                    hipLaunchKernelGGL(keccak_tree_top_kernel, dim3(1), dim3(std::max<uint32_t>(64, n0 / 2)), (size_t)n0 * 32, stream,
+                                       t->layers + t->layer_off[l - 1], n0, root_copy);
+                    P3_HIP(hipGetLastError());
+                    t->root_copied = root_copy != nullptr;
+                    break;
+                }
+            }
             hipLaunchKernelGGL(keccak_compress_kernel, dim3((uint32_t)((len + 255) / 256)), dim3(256), 0, stream,
                                t->layers + t->layer_off[l - 1], t->layers + t->layer_off[l], len, rs, rs.count > 0 ? 1u : 0u);
             P3_HIP(hipGetLastError());

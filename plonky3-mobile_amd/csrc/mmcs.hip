@@ -359,39 +359,43 @@ __global__ void __launch_bounds__(256) keccak_compress_kernel(const uint32_t* pr
     }
     store_digest64(next + i * 8, st);
 }
-// Finishes a Keccak tree whose current layer has at most 2048 digests: all remaining (injection-free) levels in ONE
-// workgroup, the current layer mirrored in LDS.  A level costs one permutation latency either way (~13 us: the 64-bit
-// lanes have no 16-lane cooperative form), but eleven launches become one — the small layers of the ~22 trees of a
-// proof were ~350 of its ~450 launches.  layer0: consecutive layers in HBM, n0 digests followed by n0/2, ...
-__global__ void __launch_bounds__(1024) keccak_tree_top_kernel(uint32_t* layer0, uint32_t n0, uint32_t* root_copy) {
+// Several levels of a Keccak tree per launch: each workgroup reduces a chunk of `chunk` <= 2048 consecutive digests of
+// the current layer by `levels` levels inside LDS and writes every intermediate layer to HBM.  A level costs one
+// permutation latency either way (~13 us: the 64-bit lanes have no 16-lane cooperative form), but up to eleven
+// launches become one — the small layers of the ~22 trees of a proof were ~350 of its ~450 launches.
+// layer0: consecutive layers in HBM (n_in digests, then n_in / 2, ...).
+__global__ void __launch_bounds__(1024) keccak_tree_levels_kernel(uint32_t* layer0, uint32_t n_in, uint32_t chunk, uint32_t levels,
+                                                                  uint32_t* root_copy) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i < n0 * 2; i += blockDim.x)
-        reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(layer0)[i];
+    const uint32_t tid = threadIdx.x, blk = blockIdx.x;
+    const uint4* src = reinterpret_cast<const uint4*>(layer0) + (size_t)blk * chunk * 2;
+    for (uint32_t i = tid; i < chunk * 2; i += blockDim.x) reinterpret_cast<uint4*>(lds)[i] = src[i];
     __syncthreads();
-    uint32_t* out = layer0 + (size_t)n0 * 8;
-    for (uint32_t n = n0; n > 1; n >>= 1) {
+    uint32_t* out = layer0 + (size_t)n_in * 8;  // next layer
+    uint32_t n_layer = n_in >> 1;               // its length
+    for (uint32_t k = 0, n = chunk; k < levels; k++, n >>= 1) {
         const uint32_t half = n >> 1;
         uint64_t st[25];
         const bool act = tid < half;
         if (act) {
             const uint64_t* p = reinterpret_cast<const uint64_t*>(lds) + (size_t)tid * 8;
 #pragma unroll
-            for (int k = 0; k < 8; k++) st[k] = p[k];
+            for (int i = 0; i < 8; i++) st[i] = p[i];
 #pragma unroll
-            for (int k = 8; k < 25; k++) st[k] = 0;
+            for (int i = 8; i < 25; i++) st[i] = 0;
             kk::permute(st);
         }
         __syncthreads();
         if (act) {
             uint64_t* p = reinterpret_cast<uint64_t*>(lds) + (size_t)tid * 4;
 #pragma unroll
-            for (int k = 0; k < 4; k++) p[k] = st[k];
-            store_digest64(out + (size_t)tid * 8, st);
-            if (half == 1 && root_copy) store_digest64(root_copy, st);
+            for (int i = 0; i < 4; i++) p[i] = st[i];
+            store_digest64(out + ((size_t)blk * half + tid) * 8, st);
+            if (n_layer == 1 && root_copy) store_digest64(root_copy, st);
         }
         __syncthreads();
-        out += (size_t)half * 8;
+        out += (size_t)n_layer * 8;
+        n_layer >>= 1;
     }
 }
 __global__ void keccak_f_kernel(uint64_t* states, uint64_t n) {
@@ -512,17 +516,19 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
         for (size_t l = 1; l < t->layer_len.size(); l++) {
             uint64_t len = t->layer_len[l];
             RowSet rs = make_rowset(*t, len);
-            if (len <= 1024) {  // the rest of the tree in one workgroup when no shorter matrix is injected any more
-                bool clean = true;
-                for (size_t k = l; k < t->layer_len.size(); k++) clean = clean && !has_height(*t, t->layer_len[k]);
-                if (clean) {
-                    const uint32_t n0 = (uint32_t)t->layer_len[l - 1];
-                    hipLaunchKernelGGL(keccak_tree_top_kernel, dim3(1), dim3(std::max<uint32_t>(64, n0 / 2)), (size_t)n0 * 32, stream,
-                                       t->layers + t->layer_off[l - 1], n0, root_copy);
-                    P3_HIP(hipGetLastError());
-                    t->root_copied = root_copy != nullptr;
-                    break;
-                }
+            if (len < COOP_MAX && !rs.count) {
+                // as many injection-free levels as one launch may take: chunks of up to 2048 digests per workgroup
+                const uint64_t n_in = t->layer_len[l - 1];
+                uint32_t levels = 0;
+                while (levels < 11 && l + levels < t->layer_len.size() && !has_height(*t, t->layer_len[l + levels])) levels++;
+                const uint32_t chunk = (uint32_t)std::min<uint64_t>(n_in, 1ull << levels);
+                while ((1u << levels) > chunk) levels--;
+                hipLaunchKernelGGL(keccak_tree_levels_kernel, dim3((uint32_t)(n_in / chunk)), dim3(std::max<uint32_t>(64, chunk / 2)),
+                                   (size_t)chunk * 32, stream, t->layers + t->layer_off[l - 1], (uint32_t)n_in, chunk, levels, root_copy);
+                P3_HIP(hipGetLastError());
+                if (t->layer_len[l + levels - 1] == 1) t->root_copied = root_copy != nullptr;
+                l += levels - 1;  // the loop's l++ completes the step
+                continue;
             }
             hipLaunchKernelGGL(keccak_compress_kernel, dim3((uint32_t)((len + 255) / 256)), dim3(256), 0, stream,
                                t->layers + t->layer_off[l - 1], t->layers + t->layer_off[l], len, rs, rs.count > 0 ? 1u : 0u);

@@ -211,7 +211,8 @@ def test_randomized_large_shapes(dft, oracle, p3):
 
 @pytest.mark.parametrize("log_h,w,ab", [(16, 2, 1), (16, 4, 2), (16, 8, 3), (17, 2, 1), (17, 4, 1), (18, 2, 2), (18, 8, 1),
                                         (19, 2, 1), (19, 4, 3), (20, 2, 1), (20, 4, 1), (20, 2, 2), (21, 2, 1), (21, 8, 1),
-                                        (22, 2, 1), (22, 4, 2), (16, 16, 1), (18, 16, 2), (19, 16, 1)])
+                                        (22, 2, 1), (22, 4, 2), (16, 16, 1), (18, 16, 2), (19, 16, 1), (17, 2, 3), (20, 2, 3), (21, 2, 2),
+                                        (23, 2, 1)])
 def test_narrow_three_launch_lde(dft, oracle, p3, log_h, w, ab):
     """The two-digit, three-launch LDE for narrow matrices (ntt_narrow.cuh; W in {2, 4, 8, 16}, 2^16..2^24 rows,
     bit-reversed output): every digit size 8..11 in both positions, every slot/row split, blowup 2, 4 and 8,

@@ -4,12 +4,18 @@ blowup 2, on N MI355X (one process per GPU; proofs are independent, so ranks sha
 data-path collective — weak scaling).
 
   python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+  python bench.py --workload cfg3|cfg5 ...                (the other single-GPU BASELINE configs, same JSON schema)
 
-A "step" proves `--batch` independent fib_air instances (a, b) = (i, i+1) per rank with all inputs
-generated in HBM.  Prints ONE JSON line on rank 0 (contract in the task statement) with two extra
-objects: `roofline` (the coset-LDE unit, algorithmic bytes 4*h*w*(1+blowup) per SURVEY.md §8d, timed
-with HIP events on the launch stream) and `cpu_baseline` (the C oracle timed on the host cores).
-"""
+Workloads (BASELINE.json `configs`):
+  cfg2 (default)  configs[1]: fib_air 2^20-row trace, blowup 2.  A "step" proves `--batch` independent instances
+                  (a, b) = (i, i+1) per rank with all inputs generated in HBM.
+  cfg3            configs[2]: fib_air 2^24-row trace, blowup 4 (FRI-fold-heavy); step = `--batch` proofs.
+  cfg5            configs[4]: the wide trace 2^16 x 2633 (benchmark_input, fib_air.rs:77-86, standing in for the
+                  Keccak-f AIR trace): step = one bit-reversed coset LDE (blowup 2) + Poseidon2 MMCS commit of
+                  the 2^17-row result.
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects: `roofline` (the
+dominant HBM-bound unit, algorithmic bytes per SURVEY.md §8d, timed with HIP events on the launch stream) and
+`cpu_baseline` (the C oracle timed on the host cores)."""
 import argparse
 import json
 import os
@@ -21,21 +27,24 @@ sys.path.insert(0, ROOT)
 # concurrent provers each own a stream; give them distinct hardware queues (ROCm default is 4)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_ACHIEVABLE_GBPS = 6300.0  # same guide: ~6.3 TB/s achievable
 
 
-def cpu_baseline(log_height, log_blowup, job, hash_kind=0):
+def cpu_baseline_fib(log_height, job, hash_kind=0):
     """The reference CPU prover (Rust + Plonky3) cannot be built here, so the baseline is the
     repo's C restatement (oracle/, kind "port"), single-threaded like the reference build
     (native/Cargo.toml:32-43 enables no `parallel` feature), timed on this host on the SAME instance.
-    Bounded sample: one full proof at the bench size (about 20-30 s of CPU at 2^20)."""
+    Bounded sample: one full proof at 2^20 (about 20 s of CPU); at larger sizes a 2^20 proof stands in and the
+    sample says so (the prover is O(n log n): the figure is NOT extrapolated)."""
     from oracle import oracle as o
     o.build()
     fp = o.FriParams(*[getattr(job.params, k) for k in ("log_blowup", "log_final_poly_len", "num_queries",
                                                          "proof_of_work_bits")])
+    sample_log = min(log_height, 20)
     o.set_threads(1)
     t0 = time.perf_counter()
-    proof = o.prove_fib_air(0, 1, log_height, fp, hash=hash_kind)
+    proof = o.prove_fib_air(0, 1, sample_log, fp, hash=hash_kind)
     dt = time.perf_counter() - t0
     # the same port with its OpenMP loops (Merkle layers, quotient, openings, folds) on every host core
     # the GPU box gives one GPU's job a share of about 16 host cores whatever nproc says
@@ -46,33 +55,50 @@ def cpu_baseline(log_height, log_blowup, job, hash_kind=0):
     cores = max(1, min(o.max_threads(), avail, int(os.environ.get("P3HIP_BENCH_CPU_THREADS", "16"))))
     o.set_threads(cores)
     t1 = time.perf_counter()
-    proof_mt = o.prove_fib_air(0, 1, log_height, fp, hash=hash_kind)
+    proof_mt = o.prove_fib_air(0, 1, sample_log, fp, hash=hash_kind)
     dt_mt = time.perf_counter() - t1
     o.set_threads(1)
-    gpu = job.prove_one(0, 1)
-    ok = o.verify_fib_air(gpu, 0, 1, o.fib_public_x(0, 1, 1 << log_height), log_height, fp, hash=hash_kind) == 0
-    return {"value": 1.0 / dt, "unit": "proofs/s", "cores": 1, "kind": "port",
-            "sample": "1 full fib_air proof, instance (a,b)=(0,1), 2^%d rows, same FRI parameters" % log_height,
-            "seconds": dt, "proof_bytes_equal_to_gpu": bool(gpu == proof), "oracle_verifier_accepts_gpu_proof": bool(ok),
-            "proof_bytes": len(proof),
-            "all_cores": {"value": 1.0 / dt_mt, "unit": "proofs/s", "cores": cores, "seconds": dt_mt,
-                          "same_bytes": bool(proof_mt == proof),
-                          "note": "same C port, OpenMP over the hashing/opening/folding loops; transforms and transcript serial"}}
+    out = {"value": 1.0 / dt, "unit": "proofs/s", "cores": 1, "kind": "port",
+           "sample": "1 full fib_air proof, instance (a,b)=(0,1), 2^%d rows, same FRI parameters" % sample_log,
+           "seconds": dt, "proof_bytes": len(proof), "build_flags": o.build_flags(),
+           "all_cores": {"value": 1.0 / dt_mt, "unit": "proofs/s", "cores": cores, "seconds": dt_mt,
+                         "same_bytes": bool(proof_mt == proof),
+                         "note": "same C port, OpenMP over the hashing/opening/folding loops; transforms and transcript serial"}}
+    if sample_log == log_height:
+        gpu = job.prove_one(0, 1)
+        out["proof_bytes_equal_to_gpu"] = bool(gpu == proof)
+        out["oracle_verifier_accepts_gpu_proof"] = bool(
+            o.verify_fib_air(gpu, 0, 1, o.fib_public_x(0, 1, 1 << log_height), log_height, fp, hash=hash_kind) == 0)
+    else:
+        out["sample"] += " (the 2^%d instance itself takes minutes on one core: a 2^%d proof is the bounded sample)" % (
+            log_height, sample_log)
+        gpu = job.prove_one(0, 1)
+        out["oracle_verifier_accepts_gpu_proof"] = bool(
+            o.verify_fib_air(gpu, 0, 1, o.fib_public_x(0, 1, 1 << log_height), log_height, fp, hash=hash_kind) == 0)
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--log-height", type=int, default=20)
-    ap.add_argument("--log-blowup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=32, help="independent proofs per rank per step")
-    ap.add_argument("--threads", type=int, default=8, help="concurrent provers (host threads/streams) per rank")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg5"], default="cfg2",
+                    help="BASELINE configs[1] (default, the headline), configs[2] or configs[4]")
+    ap.add_argument("--log-height", type=int, default=None)
+    ap.add_argument("--log-blowup", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=None, help="independent proofs per rank per step")
+    ap.add_argument("--threads", type=int, default=None, help="concurrent provers (host threads/streams) per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hash", choices=["poseidon2", "keccak"], default="poseidon2",
                     help="poseidon2 = BASELINE.json's configuration (default); keccak = the hashes the reference itself wires")
     args = ap.parse_args()
+    defaults = {"cfg2": dict(log_height=20, log_blowup=1, batch=32, threads=8, steps=10, warmup=2),
+                "cfg3": dict(log_height=24, log_blowup=2, batch=4, threads=2, steps=3, warmup=1),
+                "cfg5": dict(log_height=16, log_blowup=1, batch=1, threads=1, steps=10, warmup=2)}[args.workload]
+    for k, v in defaults.items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
 
     import torch
     import torch.distributed as dist
@@ -98,10 +124,13 @@ def main():
     if not ok:
         raise RuntimeError("no HIP backend, refusing to run a fallback: " + msg)
 
-    n = 1 << args.log_height
     from plonky3_mobile_amd import bench_support as bs
-    job = bs.FibAirJob(p3, args.log_height, args.log_blowup, args.batch, first_instance=rank * args.batch,
-                       threads=args.threads, hash=args.hash)
+    if args.workload == "cfg5":
+        job = bs.WideCommitJob(p3, args.log_height, args.log_blowup, hash=args.hash)
+    else:
+        job = bs.FibAirJob(p3, args.log_height, args.log_blowup, args.batch, first_instance=rank * args.batch,
+                           threads=args.threads, hash=args.hash, config_label={"cfg2": "configs[1]", "cfg3": "configs[2]"}.get(
+                               args.workload if (args.log_height, args.log_blowup) == (defaults["log_height"], defaults["log_blowup"]) else ""))
 
     def barrier():
         torch.cuda.synchronize()
@@ -111,17 +140,19 @@ def main():
 
     from plonky3_mobile_amd import batch as pbatch
     n_total = args.batch * world
-
-    coll_state = {"mode": ("rccl scatter/gather" if backend == "nccl" else backend + " scatter/gather (rehearsal)") if world > 1 else "none (single rank)"}
-    if os.environ.get("P3HIP_BENCH_NO_GATHER"):
+    sharded = args.workload != "cfg5" and world > 1
+    allow_local = os.environ.get("P3HIP_BENCH_ALLOW_LOCAL") == "1"
+    coll_state = {"mode": ("rccl scatter/gather" if backend == "nccl" else backend + " scatter/gather (rehearsal, not RCCL)")
+                  if sharded else ("none (single rank)" if world == 1 else "none (replicas only: one matrix per rank)")}
+    if sharded and os.environ.get("P3HIP_BENCH_NO_GATHER"):
         coll_state["mode"] = "disabled by P3HIP_BENCH_NO_GATHER: local sharding only"
 
     def one_step(k):
-        if world == 1:
+        if not sharded:
             return job.step()
         # BASELINE configs[3]: rank 0 scatters the instance descriptors, every rank proves its shard
         # (instance i -> rank i mod world), the proof bytes are gathered back on rank 0.  No other collective.
-        if "scatter/gather" in coll_state["mode"] and not coll_state["mode"].startswith("fallback"):
+        if "scatter/gather" in coll_state["mode"]:
             try:
                 inst = [(k * n_total + i, k * n_total + i + 1) for i in range(n_total)] if rank == 0 else []
                 mine = pbatch.scatter_descriptors(inst, device=coll_dev)
@@ -130,9 +161,14 @@ def main():
                 prev, coll_state["pending"] = coll_state.get("pending"), pbatch.gather_proofs_async(
                     sorted(got.items()), n_total, device=coll_dev)
                 return prev.wait() if prev is not None else None
-            except Exception as e:  # keep the scaling run alive: the sharding itself needs no collective
-                coll_state["mode"] = "fallback to local sharding (collective failed: %s)" % type(e).__name__
+            except Exception as e:
+                # A failed collective is FATAL: an N-GPU line must never be printed without RCCL having moved the
+                # batch.  P3HIP_BENCH_ALLOW_LOCAL=1 (debugging only) continues with local sharding and says so.
                 print("bench.py: scatter/gather failed on rank %d: %r" % (rank, e), file=sys.stderr)
+                if not allow_local:
+                    sys.stderr.flush()
+                    os._exit(3)
+                coll_state["mode"] = "FALLBACK to local sharding (collective failed: %s; P3HIP_BENCH_ALLOW_LOCAL=1)" % type(e).__name__
         mine = [(i, k * n_total + i) for i in pbatch.shard_instances(n_total, rank, world)]
         return job.step(mine)
 
@@ -151,25 +187,19 @@ def main():
     drain()  # the last step's proofs must be on rank 0 inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
+    ranks_info = [{"rank": rank, "local_rank": local_rank, "device_count": n_dev, "device": torch.cuda.current_device()}]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        info = torch.tensor([rank, local_rank, n_dev, torch.cuda.current_device()], dtype=torch.int64, device=coll_dev)
+        infos = [torch.empty_like(info) for _ in range(world)]
+        dist.all_gather(infos, info)
+        ranks_info = [dict(zip(("rank", "local_rank", "device_count", "device"), [int(v) for v in i.cpu().tolist()])) for i in infos]
     units = args.batch * args.steps * world
     value = units / elapsed
 
-    # ---- roofline of the dominant HBM-bound unit: the coset LDE, HIP events on the launch stream ----
-    roof = job.lde_roofline(reps=20)
-    traffic, traffic_src = None, None
-    try:  # HBM-side bytes of the same LDE unit from the committed PMC passes (not collected live)
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_lde_v2.json")) as f:
-            pmc = json.load(f)
-        key = {(20, 1): "cfg2_lde_2^20x2_blowup2", (24, 2): "cfg3_lde_2^24x2_blowup4"}.get((args.log_height, args.log_blowup))
-        if key:
-            traffic = pmc[key]["total_bytes"]
-            traffic_src = "profiles/r01_pmc_lde_v2.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, summed over the unit's three launches (tools/pmc_probe.py, tools/pmc_summarize.py)"
-    except Exception:
-        pass
+    roof = job.roofline()
     out = {
         "metric": job.metric_name(),
         "value": value,
@@ -183,39 +213,23 @@ def main():
         "vs_baseline": None,
         "dtype": "u32 (BabyBear Montgomery, 31-bit modular)",
         "data": "synthetic",
-        "config": {"workload": job.workload_name(), "log_height": args.log_height, "width": 2,
-                   "log_blowup": args.log_blowup, "hash": args.hash, "batch_per_gpu": args.batch,
-                   "concurrent_provers_per_gpu": job.threads,
-                   "fri": {"log_final_poly_len": job.params.log_final_poly_len, "num_queries": job.params.num_queries,
-                           "proof_of_work_bits": job.params.proof_of_work_bits},
-                   "parallelism": "independent proofs, instance i -> rank i mod N; RCCL only scatters descriptors / gathers proof bytes"},
-        "roofline": {"bound": "hbm", "achieved": roof["gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": roof["gbps"] / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "coset_lde_batch = narrow_inv1_kernel + narrow_mid_kernel + narrow_fwd2_kernel (one unit, three launches)", "algorithmic_bytes": roof["bytes"],
-                     "avg_us": roof["avg_us"], "concurrent_gbps": roof.get("concurrent_gbps"),
-                     "concurrent_streams": roof.get("concurrent_streams")},
-        # The kernel that dominates a proof BY TIME is Poseidon2 (12.6 M permutations per 2^20 proof, ~80 % of the GPU
-        # time) and it is integer-VALU-bound, which the contract's hbm|mfma roofline cannot express: reported here
-        # against the issue ceiling derived from the measured per-instruction rates.
-        "valu_roofline": {"kernel": "Poseidon2 leaf/compress (one state per lane, fp64 integer arithmetic)",
-                          "achieved": job.poseidon2_rate() / 1e9,
-                          "peak": 7.26, "unit": "Gperm/s", "instructions_per_permutation": 5156,
-                          "peak_basis": "5.16k wave-instructions per permutation (ISA count of compress_layer_f64_kernel), "
-                                        "nearly all fp64 VALU at 4.2 cycles each, on 1024 SIMDs at 2.4 GHz "
-                                        "(profiles/r01_microbench2_valu_issue_rates.txt)",
-                          # sustained: tools/clock_probe.hip (profiles/r01_v5_clock_probe_sustained_valu.txt) — under a
-                          # chip-wide fp64 FMA load the shader clock settles at ~1.93 GHz and a SIMD retires one fp64
-                          # wave-instruction per 4.55 of those cycles: 434 G wave-instructions/s chip-wide
-                          "sustained_peak": 434.0e9 / 4850 * 64 / 1e9,
-                          "sustained_basis": "434 G fp64 wave-instructions/s measured chip-wide under sustained load "
-                                             "(1.93 GHz x 1024 SIMDs / 4.55 cycles) / 4.85k VALU instructions per permutation"},
-        "stages_ms": job.stage_breakdown(),
+        "config": dict(job.config(), workload=job.workload_name(), hash=args.hash,
+                       parallelism=("independent proofs, instance i -> rank i mod N; RCCL only scatters descriptors / gathers proof bytes"
+                                    if args.workload != "cfg5" else "replicas only (one matrix per rank, no collective)")),
+        "roofline": roof,
         "collectives": coll_state["mode"],
+        "world_size": world,
+        "dist_backend": (backend + (" (= RCCL on ROCm)" if backend == "nccl" else "")) if world > 1 else None,
+        "ranks": ranks_info,
+        "parity": "proof bytes / digests are compared with the repo's C oracle (a restatement of upstream Plonky3 from "
+                  "recall; pinned by reference code only for the DFT): self-consistent, upstream parity UNPINNED",
     }
+    out.update(job.extra_report())
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["valu_roofline"]["frac"] = out["valu_roofline"]["achieved"] / out["valu_roofline"]["peak"]
-        out["valu_roofline"]["frac_of_sustained"] = out["valu_roofline"]["achieved"] / out["valu_roofline"]["sustained_peak"]
-        out["cpu_baseline"] = cpu_baseline(args.log_height, args.log_blowup, job, 1 if args.hash == "keccak" else 0)
+        if args.workload == "cfg5":
+            out["cpu_baseline"] = job.cpu_baseline()
+        else:
+            out["cpu_baseline"] = cpu_baseline_fib(args.log_height, job, 1 if args.hash == "keccak" else 0)
     job.close()
     if rank == 0:
         print(json.dumps(out))

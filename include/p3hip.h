@@ -10,12 +10,20 @@
  *     (native/src/backend_vulkan.rs:2002-2005); matrices are row-major height x width;
  *   - every function returns 0 on success or a negative P3HIP_ERR_* code and NEVER aborts; the message
  *     goes to a per-thread take-and-clear mailbox (native/src/gpu_dft.rs:42,65-68);
- *   - device state (tables, scratch) is per calling thread, created on first use
- *     (native/src/backend_vulkan.rs:100-124);
+ *   - device state (cached tables, scratch) belongs to the (calling thread, current device) pair and is created on
+ *     first use (native/src/backend_vulkan.rs:100-124: the reference's runtime is thread-local too).  A thread that
+ *     switches device (hipSetDevice) simply gets that device's own context; objects that own HBM (trees, provers)
+ *     remember their device and return P3HIP_ERR_BAD_ARG when used with another one current;
  *   - there is NO CPU fallback inside this library: on error the caller decides (the Rust GpuDft keeps
  *     its own Radix2DitParallel fallback, native/src/gpu_dft.rs:100-112).
  *   - `*_dev` variants take HBM pointers (hipMalloc / p3hip_malloc / a torch tensor's data_ptr) and a
- *     hipStream_t passed as void*; they enqueue and return without synchronising.
+ *     hipStream_t passed as void*; they enqueue and return without synchronising.  STREAM CONTRACT: any number of
+ *     streams may be used from one thread, also interleaved — intermediates live in scratch keyed by (thread, stream),
+ *     tables built at first use are filled by a kernel on the calling stream and guarded by an event for the others.
+ *     The exceptions to "enqueue only": the very first call of a thread on a device builds its context (blocking),
+ *     a scratch slab that has to GROW is reallocated after a device synchronise, and so is the bounded table cache
+ *     once a thread has used more than 256 distinct (shift, height) pairs.  A given stream must not be used from two
+ *     threads at once with buffers that alias.
  */
 #ifndef P3HIP_H
 #define P3HIP_H
@@ -59,6 +67,9 @@ int p3hip_free(void *dev_ptr);
 int p3hip_upload(void *dev_dst, const void *host_src, size_t bytes);
 int p3hip_download(void *host_dst, const void *dev_src, size_t bytes);
 int p3hip_sync(void *stream);
+/* Frees the calling thread's device state (tables, scratch) on every device it used, after synchronising them.
+ * Optional: worker threads that are about to exit call it so that nothing is left behind in HBM. */
+void p3hip_release_thread_context(void);
 
 /* ---- TwoAdicSubgroupDft<BabyBear> --------------------------------------------------------------- */
 /* backend_vulkan::dft_batch (backend_vulkan.rs:1988-2063) / setup_vulkan_pipeline_plan (:1028-1031):

@@ -28,6 +28,39 @@ def build(force=False):
 
 
 _lib = None
+_FLAGS = "-O2 -fopenmp (portable build, oracle/Makefile CFLAGS)"
+
+
+def build_flags():
+    """Compiler flags of the library currently loaded (reported in bench.py's cpu_baseline)."""
+    return _FLAGS
+
+
+def use_native():
+    """bench.py's cpu_baseline leg only: switch to a -O3 -march=native build of the same sources, compiled on THIS
+    host (keyed by its CPU flags, so a build made on another machine is never loaded).  Falls back to the portable
+    build (and says so in build_flags()) when the compiler is missing."""
+    global _lib, _LIB_PATH, _FLAGS
+    import hashlib
+    try:
+        with open("/proc/cpuinfo") as f:
+            flags = next((ln for ln in f if ln.startswith("flags")), "")
+    except OSError:
+        flags = ""
+    key = hashlib.sha1(flags.encode()).hexdigest()[:12]
+    ndir = os.path.join(_HERE, "_build", "native-" + key)
+    path = os.path.join(ndir, "libp3oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    try:
+        if not (os.path.exists(path) and all(os.path.getmtime(s) <= os.path.getmtime(path) for s in srcs)):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "native", "NATIVE_DIR=" + ndir])
+    except Exception as e:  # keep the baseline alive on the portable build
+        _FLAGS = "-O2 -fopenmp (portable build; the native build failed: %s)" % type(e).__name__
+        return False
+    _LIB_PATH, _lib = path, None
+    _FLAGS = "-O3 -march=native -fopenmp (built on the timing host, oracle/Makefile `native`)"
+    lib()
+    return True
 
 
 def lib():

@@ -19,6 +19,7 @@ _SIGS = {
     "p3hip_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "p3hip_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "p3hip_sync": (C.c_int, [C.c_void_p]),
+    "p3hip_release_thread_context": (None, []),
     "p3hip_dft_batch_bb31": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
     "p3hip_idft_batch_bb31": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
     "p3hip_coset_dft_batch_bb31": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32]),

@@ -108,6 +108,7 @@ int p3hip_sync(void* stream) {
     P3_HIP(hipStreamSynchronize((hipStream_t)stream));
     return OK;
 }
+void p3hip_release_thread_context(void) { release_thread_contexts(); }
 
 }  // extern "C"
 
@@ -146,15 +147,15 @@ static int dft_host(DftOp op, const uint32_t* in, uint32_t* out, size_t h, size_
         size_t in_bytes = h * w * 4;
         size_t out_rows = op == OP_COSET_LDE ? (h << added_bits) : h;
         size_t out_bytes = out_rows * w * 4;
-        rc = cx->ws[2].reserve(in_bytes);
-        if (rc) return rc;
-        rc = cx->ws[3].reserve(out_bytes);
-        if (rc) return rc;
         hipStream_t stream = nullptr;
-        P3_HIP(hipMemcpyAsync(cx->ws[2].ptr, in, in_bytes, hipMemcpyHostToDevice, stream));
-        rc = dft_dev(op, cx->ws[2].as<uint32_t>(), cx->ws[3].as<uint32_t>(), h, w, added_bits, shift, br_out, stream);
+        rc = cx->ws(stream, 2).reserve(in_bytes);
         if (rc) return rc;
-        P3_HIP(hipMemcpyAsync(out, cx->ws[3].ptr, out_bytes, hipMemcpyDeviceToHost, stream));
+        rc = cx->ws(stream, 3).reserve(out_bytes);
+        if (rc) return rc;
+        P3_HIP(hipMemcpyAsync(cx->ws(stream, 2).ptr, in, in_bytes, hipMemcpyHostToDevice, stream));
+        rc = dft_dev(op, cx->ws(stream, 2).as<uint32_t>(), cx->ws(stream, 3).as<uint32_t>(), h, w, added_bits, shift, br_out, stream);
+        if (rc) return rc;
+        P3_HIP(hipMemcpyAsync(out, cx->ws(stream, 3).ptr, out_bytes, hipMemcpyDeviceToHost, stream));
         P3_HIP(hipStreamSynchronize(stream));
         return OK;
     });
@@ -225,12 +226,13 @@ int p3hip_poseidon2_permute(uint32_t* states, size_t n) {
         Context* cx;
         int rc = get_context(&cx);
         if (rc) return rc;
-        rc = cx->ws[2].reserve(n * 64);
+        hipStream_t stream = nullptr;
+        rc = cx->ws(stream, 2).reserve(n * 64);
         if (rc) return rc;
-        P3_HIP(hipMemcpy(cx->ws[2].ptr, states, n * 64, hipMemcpyHostToDevice));
-        rc = poseidon2_permute_states(nullptr, cx->ws[2].as<uint32_t>(), n);
+        P3_HIP(hipMemcpy(cx->ws(stream, 2).ptr, states, n * 64, hipMemcpyHostToDevice));
+        rc = poseidon2_permute_states(stream, cx->ws(stream, 2).as<uint32_t>(), n);
         if (rc) return rc;
-        P3_HIP(hipMemcpy(states, cx->ws[2].ptr, n * 64, hipMemcpyDeviceToHost));
+        P3_HIP(hipMemcpy(states, cx->ws(stream, 2).ptr, n * 64, hipMemcpyDeviceToHost));
         return OK;
     });
 }
@@ -302,6 +304,10 @@ int p3hip_mmcs_open_batch(const p3hip_tree_t* tree, size_t index, uint32_t* rows
                           void* stream) {
     return guarded([&]() -> int {
         if (!tree) return fail(ERR_BAD_ARG, "mmcs_open_batch: null tree");
+        size_t row_words = 0;
+        for (size_t w : tree->t->widths) row_words += w;
+        if ((row_words && !rows_out) || (tree->t->log_max_height && !path_out))
+            return fail(ERR_BAD_ARG, "mmcs_open_batch: null output buffer");
         return mmcs_open((hipStream_t)stream, *tree->t, index, rows_out, path_out);
     });
 }
@@ -369,7 +375,7 @@ int p3hip_fib_prover_create_hash(int hash, unsigned log_n, const p3hip_fri_param
         }
         std::unique_ptr<p3hip_fib_prover> p(new p3hip_fib_prover());
         FriParams fp{params->log_blowup, params->log_final_poly_len, params->num_queries, params->proof_of_work_bits};
-        rc = p->prover.init(log_n, fp, st, own, hash);
+        rc = p->prover.init(log_n, fp, st, own, hash);  // on failure the prover's destructor destroys the owned stream
         if (rc) return rc;
         *out = p.release();
         return OK;
@@ -422,6 +428,7 @@ int p3hip_verify_fib_air_hash(int hash, const uint8_t* proof, size_t len, uint64
 struct p3hip_fib_batch {
     unsigned log_n = 0;
     int hash = HASH_POSEIDON2;
+    int device = 0;  // the creator's current device: HIP's current device is per thread and defaults to 0
     FriParams fp{};
     std::vector<std::thread> workers;
     std::mutex mu;
@@ -437,11 +444,28 @@ struct p3hip_fib_batch {
     std::string error_text;
 
     void worker_main() {
-        FibProver prover;
-        hipStream_t st = nullptr;
-        int rc = get_context_status();
-        if (rc == OK && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) rc = fail(ERR_HIP, "hipStreamCreateWithFlags failed");
-        if (rc == OK) rc = prover.init(log_n, fp, st, true, hash);
+        {
+            FibProver prover;
+            worker_loop(prover);
+        }  // the prover (arena, stream) is gone before the thread's tables and scratch are freed
+        release_thread_contexts();
+    }
+    // a std::thread whose function throws calls std::terminate: every failure becomes first_error instead
+    template <class F>
+    static int no_throw(F&& f) {
+        try { return f(); }
+        catch (const std::exception& e) { return fail(ERR_INTERNAL, std::string("exception: ") + e.what()); }
+        catch (...) { return fail(ERR_INTERNAL, "unknown exception"); }
+    }
+    void worker_loop(FibProver& prover) {
+        int rc = no_throw([&]() -> int {
+            if (hipSetDevice(device) != hipSuccess) return fail(ERR_HIP, "hipSetDevice failed in a batch worker");
+            int r = get_context_status();
+            if (r) return r;
+            hipStream_t st = nullptr;
+            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return fail(ERR_HIP, "hipStreamCreateWithFlags failed");
+            return prover.init(log_n, fp, st, true, hash);
+        });
         {
             std::unique_lock<std::mutex> lk(mu);
             if (rc != OK && first_error == 0) { first_error = rc; std::string t; take_error(&t); error_text = t; }
@@ -459,7 +483,7 @@ struct p3hip_fib_batch {
                 i = next++;
             }
             int prc = rc;
-            if (prc == OK) prc = prover.prove(a[i], b[i], &proofs[i]);
+            if (prc == OK) prc = no_throw([&]() -> int { return prover.prove(a[i], b[i], &proofs[i]); });
             {
                 std::unique_lock<std::mutex> lk(mu);
                 if (prc != OK && first_error == 0) { first_error = prc; std::string t; take_error(&t); error_text = t; }
@@ -485,6 +509,7 @@ int p3hip_fib_batch_create_hash(int hash, unsigned log_n, const p3hip_fri_params
         std::unique_ptr<p3hip_fib_batch> bt(new p3hip_fib_batch());
         bt->log_n = log_n;
         bt->hash = hash;
+        P3_HIP(hipGetDevice(&bt->device));
         bt->fp = FriParams{params->log_blowup, params->log_final_poly_len, params->num_queries, params->proof_of_work_bits};
         for (unsigned t = 0; t < n_provers; t++) bt->workers.emplace_back([p = bt.get()] { p->worker_main(); });
         {

@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #include <map>
+#include <set>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -47,21 +48,45 @@ struct TwoLevelTable {  // value(e) = lo[e & (2^T - 1)] * hi[e >> T]
     uint32_t T = 0;
 };
 
+struct CachedTable {  // a table built by a kernel on `built_on`; other streams wait for `ready` until it has completed
+    TwoLevelTable t;
+    hipEvent_t ready = nullptr;
+    hipStream_t built_on = nullptr;
+    bool complete = false;
+};
+
+// Device state of ONE (host thread, device) pair: cached tables and scratch.  Scratch slabs are keyed by the stream
+// the work is enqueued on, so calls issued from one thread on different streams never share an intermediate.
 struct Context {
     int device = -1;
     uint32_t* tile_tw[2] = {nullptr, nullptr};  // [inverse]: reference-layout stage tables, 2^12-1 words
-    std::map<std::pair<uint32_t, int>, TwoLevelTable> root_tables;            // (q, inverse) -> w_{2^q}^e
-    std::map<std::tuple<uint32_t, uint32_t, uint32_t>, TwoLevelTable> scale_tables;  // (base, log_n, mult)
-    DevBuf ws[4];  // scratch slabs (ntt ping-pong, lde coefficients, ...)
-    int init();
-    int get_root_table(uint32_t q, bool inverse, TwoLevelTable* out);
+    std::map<std::pair<uint32_t, int>, CachedTable> root_tables;                   // (q, inverse) -> w_{2^q}^e
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t>, CachedTable> scale_tables;  // (base, log_n, mult)
+    std::map<std::pair<hipStream_t, int>, DevBuf> scratch;                         // (stream, slot)
+    std::set<const void*> attr_done;  // kernels whose dynamic-LDS limit has been raised on this device
+    std::map<uint32_t, CachedTable> selector_tables;  // prover.hip: log_n -> selectors on the quotient coset (t.lo)
+    int init(int dev);
+    // scratch slab `slot` of the calling thread for work enqueued on `stream`
+    DevBuf& ws(hipStream_t stream, int slot);
+    // enqueue-only: the table is built by a kernel on `stream` at first use and cached
+    int get_root_table(hipStream_t stream, uint32_t q, bool inverse, TwoLevelTable* out);
     // value(j) = mult * base^j for j < 2^log_n
-    int get_scale_table(uint32_t base, uint32_t log_n, uint32_t mult, TwoLevelTable* out);
+    int get_scale_table(hipStream_t stream, uint32_t base, uint32_t log_n, uint32_t mult, TwoLevelTable* out);
+    // Call at the TOP of an entry point that will fetch up to `k` scale tables: if the bounded cache cannot take
+    // them it is emptied HERE (device synchronised first), never between two fetches of one call.
+    int reserve_scale_slots(size_t k);
+    // records `ready` after the kernel that fills a freshly built entry / makes `stream` wait for an entry built elsewhere
+    int mark_built(hipStream_t stream, CachedTable& e);
+    int wait_ready(hipStream_t stream, CachedTable& e);
+    // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel on this context's device
+    int ensure_dynamic_lds(const void* kernel, int bytes);
     ~Context();
 };
 
-// Per-thread context, created on first use.
+// Context of the calling thread for the CURRENT device (hipGetDevice), created on first use.
 int get_context(Context** out);
+// Frees every context of the calling thread (tables, scratch).  Worker threads call it before they exit.
+void release_thread_contexts();
 
 // ---- ntt.hip ----
 // All pointers are device pointers; launches are enqueued on `stream` and not synchronised.

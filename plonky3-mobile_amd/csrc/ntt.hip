@@ -507,7 +507,7 @@ std::vector<uint32_t> split_digits(uint32_t n) {
 }
 
 template <int LOG_RUN, int LOG_R, int MODE>
-int launch_pass_m(hipStream_t stream, const PassArgs& a, uint32_t blocks) {
+int launch_pass_m(Context& cx, hipStream_t stream, const PassArgs& a, uint32_t blocks) {
     constexpr uint32_t RUN = 1u << LOG_RUN;
     uint32_t npts = 1u << a.b;
     uint32_t threads = (npts * RUN) >> LOG_R;
@@ -515,12 +515,7 @@ int launch_pass_m(hipStream_t stream, const PassArgs& a, uint32_t blocks) {
     if (threads > (LOG_RUN == 3 ? 256u : 1024u)) return fail(ERR_INTERNAL, "ntt: tile needs more threads than the kernel's launch bound");
     size_t lds = (size_t)npts * (RUN + 1) * 4 + (size_t)npts * 4;
     auto kern = ntt_pass_kernel<LOG_RUN, LOG_R, MODE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        P3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   160 * 1024));
-        attr_set = true;
-    }
+    { int rc = cx.ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024); if (rc) return rc; }
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, stream, a);
     P3_HIP(hipGetLastError());
     return OK;
@@ -536,31 +531,27 @@ inline int pass_mode(const PassArgs& a) {
 }
 // specialised shapes only for the tile geometries the plans actually pick; everything else runs MODE 0
 template <int LOG_RUN, int LOG_R, bool FAST>
-int launch_pass_t(hipStream_t stream, const PassArgs& a, uint32_t blocks) {
+int launch_pass_t(Context& cx, hipStream_t stream, const PassArgs& a, uint32_t blocks) {
     if constexpr (FAST) {
         switch (pass_mode(a)) {
-            case 1: return launch_pass_m<LOG_RUN, LOG_R, 1>(stream, a, blocks);
-            case 2: return launch_pass_m<LOG_RUN, LOG_R, 2>(stream, a, blocks);
-            case 3: return launch_pass_m<LOG_RUN, LOG_R, 3>(stream, a, blocks);
-            case 4: return launch_pass_m<LOG_RUN, LOG_R, 4>(stream, a, blocks);
-            case 5: return launch_pass_m<LOG_RUN, LOG_R, 5>(stream, a, blocks);
+            case 1: return launch_pass_m<LOG_RUN, LOG_R, 1>(cx, stream, a, blocks);
+            case 2: return launch_pass_m<LOG_RUN, LOG_R, 2>(cx, stream, a, blocks);
+            case 3: return launch_pass_m<LOG_RUN, LOG_R, 3>(cx, stream, a, blocks);
+            case 4: return launch_pass_m<LOG_RUN, LOG_R, 4>(cx, stream, a, blocks);
+            case 5: return launch_pass_m<LOG_RUN, LOG_R, 5>(cx, stream, a, blocks);
             default: break;
         }
     }
-    return launch_pass_m<LOG_RUN, LOG_R, 0>(stream, a, blocks);
+    return launch_pass_m<LOG_RUN, LOG_R, 0>(cx, stream, a, blocks);
 }
 
 template <int B, int MODE>
-int launch_fast_t(hipStream_t stream, const PassArgs& a, uint32_t blocks) {
+int launch_fast_t(Context& cx, hipStream_t stream, const PassArgs& a, uint32_t blocks) {
     constexpr uint32_t NPTS = 1u << B, NR = B >= 9 ? 32 : 16;
     size_t lds = (size_t)NPTS * 33 * 4 + (size_t)NPTS * 4;
     if constexpr (B >= 9) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            P3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_fast_kernel<B, MODE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
+        int rc = cx.ensure_dynamic_lds(reinterpret_cast<const void*>(ntt_fast_kernel<B, MODE>), 160 * 1024);
+        if (rc) return rc;
     }
     hipLaunchKernelGGL((ntt_fast_kernel<B, MODE>), dim3(blocks), dim3(NPTS * 32 / NR), lds, stream, a);
     P3_HIP(hipGetLastError());
@@ -574,7 +565,7 @@ int launch_fast_group_t(hipStream_t stream, const PassArgs& a, uint32_t blocks) 
     P3_HIP(hipGetLastError());
     return OK;
 }
-int launch_fast(hipStream_t stream, const PassArgs& a, uint32_t blocks, int mode) {
+int launch_fast(Context& cx, hipStream_t stream, const PassArgs& a, uint32_t blocks, int mode) {
     if (mode == 1) {
         switch (a.b) {
             case 6: return launch_fast_group_t<6, 1>(stream, a, blocks);
@@ -591,23 +582,23 @@ int launch_fast(hipStream_t stream, const PassArgs& a, uint32_t blocks, int mode
     }
     if (mode == 2) {
         switch (a.b) {
-            case 6: return launch_fast_t<6, 2>(stream, a, blocks);
-            case 7: return launch_fast_t<7, 2>(stream, a, blocks);
-            case 8: return launch_fast_t<8, 2>(stream, a, blocks);
-            case 9: return launch_fast_t<9, 2>(stream, a, blocks);
-            default: return launch_fast_t<10, 2>(stream, a, blocks);
+            case 6: return launch_fast_t<6, 2>(cx, stream, a, blocks);
+            case 7: return launch_fast_t<7, 2>(cx, stream, a, blocks);
+            case 8: return launch_fast_t<8, 2>(cx, stream, a, blocks);
+            case 9: return launch_fast_t<9, 2>(cx, stream, a, blocks);
+            default: return launch_fast_t<10, 2>(cx, stream, a, blocks);
         }
     }
     switch (a.b) {
-        case 6: return launch_fast_t<6, 3>(stream, a, blocks);
-        case 7: return launch_fast_t<7, 3>(stream, a, blocks);
-        case 8: return launch_fast_t<8, 3>(stream, a, blocks);
-        case 9: return launch_fast_t<9, 3>(stream, a, blocks);
-        default: return launch_fast_t<10, 3>(stream, a, blocks);
+        case 6: return launch_fast_t<6, 3>(cx, stream, a, blocks);
+        case 7: return launch_fast_t<7, 3>(cx, stream, a, blocks);
+        case 8: return launch_fast_t<8, 3>(cx, stream, a, blocks);
+        case 9: return launch_fast_t<9, 3>(cx, stream, a, blocks);
+        default: return launch_fast_t<10, 3>(cx, stream, a, blocks);
     }
 }
 
-int launch_pass(hipStream_t stream, PassArgs& a) {
+int launch_pass(Context& cx, hipStream_t stream, PassArgs& a) {
     // geometry
     static int force_run = [] { const char* e = getenv("P3HIP_NTT_LOGRUN"); return e ? atoi(e) : 0; }();
     uint32_t log_run = a.b >= 11 ? 4 : 5;
@@ -640,30 +631,30 @@ int launch_pass(hipStream_t stream, PassArgs& a) {
         if (mode == 2 || mode == 3) {
             const uint32_t rows_per_lane = a.b >= 9 ? 32 : 16;
             if (mode == 3 && a.has_sc) a.sc_step = bb::pow(a.sc_base, (uint64_t)((1u << a.b) / rows_per_lane) << a.s0);
-            return launch_fast(stream, a, nb, mode);
+            return launch_fast(cx, stream, a, nb, mode);
         }
         if (a.b > 8) goto general;
         // group-side passes: narrow widths must be powers of two for the shift-based column-wise copy
-        if ((mode == 1 || (mode == 4 && !a.has_sc)) && (a.W >= 32 || a.wshift != 0xffffffffu)) return launch_fast(stream, a, nb, mode);
+        if ((mode == 1 || (mode == 4 && !a.has_sc)) && (a.W >= 32 || a.wshift != 0xffffffffu)) return launch_fast(cx, stream, a, nb, mode);
     }
 general:
-    if (log_run == 3) return launch_pass_t<3, 5, false>(stream, a, nb);
-    if (log_run == 4) return launch_pass_t<4, 5, false>(stream, a, nb);
+    if (log_run == 3) return launch_pass_t<3, 5, false>(cx, stream, a, nb);
+    if (log_run == 4) return launch_pass_t<4, 5, false>(cx, stream, a, nb);
     uint32_t log_r = a.b >= 10 ? 5 : (a.b >= 4 ? 4 : a.b);
     switch (log_r) {
-        case 5: return launch_pass_t<5, 5, false>(stream, a, nb);
-        case 4: return launch_pass_t<5, 4, true>(stream, a, nb);
-        case 3: return launch_pass_t<5, 3, false>(stream, a, nb);
-        case 2: return launch_pass_t<5, 2, false>(stream, a, nb);
-        default: return launch_pass_t<5, 1, false>(stream, a, nb);
+        case 5: return launch_pass_t<5, 5, false>(cx, stream, a, nb);
+        case 4: return launch_pass_t<5, 4, true>(cx, stream, a, nb);
+        case 3: return launch_pass_t<5, 3, false>(cx, stream, a, nb);
+        case 2: return launch_pass_t<5, 2, false>(cx, stream, a, nb);
+        default: return launch_pass_t<5, 1, false>(cx, stream, a, nb);
     }
 }
 
-int set_twiddle(Context& cx, PassArgs& a, bool inverse) {
+int set_twiddle(Context& cx, hipStream_t stream, PassArgs& a, bool inverse) {
     a.has_tw = a.s0 > 0;
     if (!a.has_tw) return OK;
     TwoLevelTable t;
-    int rc = cx.get_root_table(a.s0 + a.b, inverse, &t);
+    int rc = cx.get_root_table(stream, a.s0 + a.b, inverse, &t);
     if (rc) return rc;
     a.tw_lo = t.lo; a.tw_hi = t.hi; a.tw_T = t.T;
     return OK;
@@ -681,10 +672,10 @@ int run_dit(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* dst,
         a.src_rows = 1ull << n;
         if (i == 0) { a.src = src; a.dst = dst; a.load_kind = SIDE_STRIDED; a.store_kind = SIDE_GROUP_REV; }
         else { a.src = dst; a.dst = dst; a.load_kind = SIDE_INPLACE; a.store_kind = SIDE_INPLACE; }
-        int rc = set_twiddle(cx, a, inverse);
+        int rc = set_twiddle(cx, stream, a, inverse);
         if (rc) return rc;
         if (i + 1 == digits.size() && has_us) { a.has_us = 1; a.uscale = uscale; }
-        rc = launch_pass(stream, a);
+        rc = launch_pass(cx, stream, a);
         if (rc) return rc;
         s0 += digits[i];
     }
@@ -701,9 +692,9 @@ int run_dif(Context& cx, hipStream_t stream, const uint32_t* src, uint64_t src_r
     // scratch -> dst.  (Bit-reversed output stays in place: every pass rewrites exactly the rows it read.)
     uint32_t* work = dst;
     if (natural_out && digits.size() > 1) {
-        int rc = cx.ws[0].reserve(((size_t)W << n) * 4);
+        int rc = cx.ws(stream, 0).reserve(((size_t)W << n) * 4);
         if (rc) return rc;
-        work = cx.ws[0].as<uint32_t>();
+        work = cx.ws(stream, 0).as<uint32_t>();
     }
     uint32_t s0 = n;
     for (size_t ii = digits.size(); ii-- > 0;) {
@@ -719,9 +710,9 @@ int run_dif(Context& cx, hipStream_t stream, const uint32_t* src, uint64_t src_r
         if (!last) { a.load_kind = SIDE_INPLACE; a.store_kind = SIDE_INPLACE; }
         else if (natural_out) { a.load_kind = SIDE_GROUP_REV; a.store_kind = SIDE_STRIDED; }
         else { a.load_kind = SIDE_GROUP; a.store_kind = SIDE_GROUP; }
-        int rc = set_twiddle(cx, a, inverse);
+        int rc = set_twiddle(cx, stream, a, inverse);
         if (rc) return rc;
-        rc = launch_pass(stream, a);
+        rc = launch_pass(cx, stream, a);
         if (rc) return rc;
     }
     return OK;
@@ -755,9 +746,9 @@ int lde_fused(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* ds
     if (bi < 6) return 1;  // kernels instantiated for BI in {6, 7}
     const uint64_t N = 1ull << n;
     size_t bytes = N * W * 4;
-    int rc = cx.ws[1].reserve(bytes);
+    int rc = cx.ws(stream, 1).reserve(bytes);
     if (rc) return rc;
-    uint32_t* coeffs = cx.ws[1].as<uint32_t>();
+    uint32_t* coeffs = cx.ws(stream, 1).as<uint32_t>();
     // inverse passes 1 and 2 (digits e1, e2) of the DIT plan
     {
         uint32_t digits[2] = {e1, e2};
@@ -769,9 +760,9 @@ int lde_fused(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* ds
             a.src_rows = N;
             if (i == 0) { a.src = src; a.dst = coeffs; a.load_kind = SIDE_STRIDED; a.store_kind = SIDE_GROUP_REV; }
             else { a.src = coeffs; a.dst = coeffs; a.load_kind = SIDE_INPLACE; a.store_kind = SIDE_INPLACE; }
-            rc = set_twiddle(cx, a, true);
+            rc = set_twiddle(cx, stream, a, true);
             if (rc) return rc;
-            rc = launch_pass(stream, a);
+            rc = launch_pass(cx, stream, a);
             if (rc) return rc;
             s += digits[i];
         }
@@ -785,10 +776,10 @@ int lde_fused(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* ds
         a.tile_tw = cx.tile_tw[1];
         a.tile_tw2 = cx.tile_tw[0];
         TwoLevelTable ti, tf, sc;
-        if ((rc = cx.get_root_table(s0 + bi, true, &ti))) return rc;
-        if ((rc = cx.get_root_table(s0 + e3, false, &tf))) return rc;
+        if ((rc = cx.get_root_table(stream, s0 + bi, true, &ti))) return rc;
+        if ((rc = cx.get_root_table(stream, s0 + e3, false, &tf))) return rc;
         uint32_t hinv = bb::inv(bb::to_monty((uint32_t)N));
-        if ((rc = cx.get_scale_table(shift, n, hinv, &sc))) return rc;
+        if ((rc = cx.get_scale_table(stream, shift, n, hinv, &sc))) return rc;
         a.tw_lo = ti.lo; a.tw_hi = ti.hi; a.tw_T = ti.T;
         a.tw2_lo = tf.lo; a.tw2_hi = tf.hi; a.tw2_T = tf.T;
         a.sc_lo = sc.lo; a.sc_hi = sc.hi; a.sc_T = sc.T;
@@ -809,22 +800,22 @@ int lde_fused(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* ds
         a.tile_tw = cx.tile_tw[0];
         a.src = dst; a.dst = dst; a.src_rows = 1ull << m;
         a.load_kind = SIDE_INPLACE; a.store_kind = SIDE_INPLACE;
-        if ((rc = set_twiddle(cx, a, false))) return rc;
-        if ((rc = launch_pass(stream, a))) return rc;
+        if ((rc = set_twiddle(cx, stream, a, false))) return rc;
+        if ((rc = launch_pass(cx, stream, a))) return rc;
         PassArgs b{};
         b.W = W; b.n = m; b.b = e1; b.s0 = 0; b.dif = 1;
         b.tile_tw = cx.tile_tw[0];
         b.src = dst; b.dst = dst; b.src_rows = 1ull << m;
         b.load_kind = SIDE_GROUP; b.store_kind = SIDE_GROUP;
-        if ((rc = set_twiddle(cx, b, false))) return rc;
-        if ((rc = launch_pass(stream, b))) return rc;
+        if ((rc = set_twiddle(cx, stream, b, false))) return rc;
+        if ((rc = launch_pass(cx, stream, b))) return rc;
     }
     return OK;
 }
 
 
 template <int B, int LQ, int VW, int K>
-int launch_narrow_t(hipStream_t stream, const NarrowArgs& a, uint32_t blocks) {
+int launch_narrow_t(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t blocks) {
     // padded tile (17 rows per 16 points; the middle kernel alternates two below 1024 threads) + stage-table prefixes
     constexpr size_t tile_bytes = ((size_t)4 * VW * narrow::lds_rows(B)) << LQ;
     // the middle kernel of 512-thread pair tiles runs column-sequentially (one pair tile, two workgroups per CU)
@@ -837,11 +828,8 @@ int launch_narrow_t(hipStream_t stream, const NarrowArgs& a, uint32_t blocks) {
     else if constexpr (K == 2) kern = narrow_mid_kernel<B, LQ, VW, SEQ>;
     else kern = narrow_fwd2_kernel<B, LQ, VW>;
     if constexpr (lds > 64 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            P3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
+        int rc = cx.ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds);
+        if (rc) return rc;
     }
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(1u << (B - 4 + LQ)), lds, stream, a);
     P3_HIP(hipGetLastError());
@@ -851,19 +839,19 @@ int launch_narrow_t(hipStream_t stream, const NarrowArgs& a, uint32_t blocks) {
 // Tile rows are 32 bytes (LQ = 2 for pairs, 3 for single words), 16 bytes for 12-stage digits (64 KB tiles, <= 1024 threads).
 constexpr int narrow_lq(int b, int vw) { return (b == 12 ? 1 : 2) + (vw == 1 ? 1 : 0); }
 template <int K, int VW>
-int launch_narrow_v(hipStream_t stream, const NarrowArgs& a, uint32_t b, uint32_t blocks) {
+int launch_narrow_v(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t b, uint32_t blocks) {
     switch (b) {
-        case 8: return launch_narrow_t<8, narrow_lq(8, VW), VW, K>(stream, a, blocks);
-        case 9: return launch_narrow_t<9, narrow_lq(9, VW), VW, K>(stream, a, blocks);
-        case 10: return launch_narrow_t<10, narrow_lq(10, VW), VW, K>(stream, a, blocks);
-        case 11: return launch_narrow_t<11, narrow_lq(11, VW), VW, K>(stream, a, blocks);
-        case 12: return launch_narrow_t<12, narrow_lq(12, VW), VW, K>(stream, a, blocks);
+        case 8: return launch_narrow_t<8, narrow_lq(8, VW), VW, K>(cx, stream, a, blocks);
+        case 9: return launch_narrow_t<9, narrow_lq(9, VW), VW, K>(cx, stream, a, blocks);
+        case 10: return launch_narrow_t<10, narrow_lq(10, VW), VW, K>(cx, stream, a, blocks);
+        case 11: return launch_narrow_t<11, narrow_lq(11, VW), VW, K>(cx, stream, a, blocks);
+        case 12: return launch_narrow_t<12, narrow_lq(12, VW), VW, K>(cx, stream, a, blocks);
         default: return fail(ERR_INTERNAL, "lde_narrow: digit out of range");
     }
 }
 template <int K>
-int launch_narrow(hipStream_t stream, const NarrowArgs& a, uint32_t b, uint32_t blocks, int vw) {
-    return vw == 1 ? launch_narrow_v<K, 1>(stream, a, b, blocks) : launch_narrow_v<K, 2>(stream, a, b, blocks);
+int launch_narrow(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t b, uint32_t blocks, int vw) {
+    return vw == 1 ? launch_narrow_v<K, 1>(cx, stream, a, b, blocks) : launch_narrow_v<K, 2>(cx, stream, a, b, blocks);
 }
 
 // Narrow-matrix coset LDE in three launches (ntt_narrow.cuh).  Returns 1 when the shape is not covered.
@@ -885,9 +873,9 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     // measured (tools/lde_sweep.py): single columns win by 15-25 % up to 2^19 rows (1-2 waves per SIMD otherwise), only
     // for the middle kernel at 2^20 (26.5 -> 23.7 us), and lose from 2^21 on (the grid is full; twice the twiddle work)
     for (int k = 0; k < 3; k++) vw[k] = force_vw == 1 || force_vw == 2 ? force_vw : (n <= 19 || (n == 20 && k == 1) ? 1 : 2);
-    int rc = cx.ws[1].reserve(N * W * 4);
+    int rc = cx.ws(stream, 1).reserve(N * W * 4);
     if (rc) return rc;
-    uint32_t* T = cx.ws[1].as<uint32_t>();
+    uint32_t* T = cx.ws(stream, 1).as<uint32_t>();
     NarrowArgs a{};
     static int use_blocked = [] { const char* e = getenv("P3HIP_NTT_NARROW_BLOCKED"); return e ? atoi(e) : 1; }();
     static int use_handover = [] { const char* e = getenv("P3HIP_NTT_NARROW_HANDOVER"); return e ? atoi(e) : 0; }();
@@ -896,8 +884,8 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     a.mid_handover = use_handover;
     a.n = n; a.n1 = n1; a.n2 = n2; a.W = W; a.added = added;
     TwoLevelTable ti, tf;
-    if ((rc = cx.get_root_table(n, true, &ti))) return rc;
-    if ((rc = cx.get_root_table(n, false, &tf))) return rc;
+    if ((rc = cx.get_root_table(stream, n, true, &ti))) return rc;
+    if ((rc = cx.get_root_table(stream, n, false, &tf))) return rc;
     auto geometry = [&](int k, uint32_t b, uint64_t rows) -> uint32_t {  // sets wsl / xcd_remap, returns the tile count
         const uint32_t slots_per_row = W / vw[k];
         a.wsl = log2u(slots_per_row);
@@ -912,7 +900,7 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     a.stage_tw = cx.tile_tw[1];
     a.tw_lo = ti.lo; a.tw_hi = ti.hi; a.tw_T = ti.T;
     uint32_t tiles = geometry(0, n1, 1ull << n2);
-    if ((rc = launch_narrow<1>(stream, a, n1, tiles, vw[0]))) return rc;
+    if ((rc = launch_narrow<1>(cx, stream, a, n1, tiles, vw[0]))) return rc;
     // K2
     a.src = T; a.dst = dst;
     a.stage_tw = cx.tile_tw[1]; a.stage_tw_fwd = cx.tile_tw[0];
@@ -922,18 +910,18 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     uint32_t base = shift;
     for (uint32_t j = 0; j < (1u << added); j++) {
         TwoLevelTable sc;
-        if ((rc = cx.get_scale_table(base, n, hinv, &sc))) return rc;
+        if ((rc = cx.get_scale_table(stream, base, n, hinv, &sc))) return rc;
         a.sc_lo[j] = sc.lo; a.sc_hi[j] = sc.hi; a.sc_T = sc.T;
         a.sc_phi[j] = bb::pow(base, 1ull << (n1 + n2 - 4));
         base = bb::mul(base, g);
     }
     tiles = geometry(1, n2, 1ull << n1);
-    if ((rc = launch_narrow<2>(stream, a, n2, tiles, vw[1]))) return rc;
+    if ((rc = launch_narrow<2>(cx, stream, a, n2, tiles, vw[1]))) return rc;
     // K3
     a.src = dst; a.dst = dst;
     a.stage_tw = cx.tile_tw[0];
     tiles = geometry(2, n1, (1ull << added) << n2);
-    return launch_narrow<3>(stream, a, n1, tiles, vw[2]);
+    return launch_narrow<3>(cx, stream, a, n1, tiles, vw[2]);
 }
 
 }  // namespace
@@ -950,10 +938,10 @@ int ntt_dft(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* dst,
         return OK;
     }
     if (src == dst) {  // the gathering first pass is out of place
-        int rc = cx.ws[0].reserve(bytes);
+        int rc = cx.ws(stream, 0).reserve(bytes);
         if (rc) return rc;
-        P3_HIP(hipMemcpyAsync(cx.ws[0].ptr, src, bytes, hipMemcpyDeviceToDevice, stream));
-        src = cx.ws[0].as<uint32_t>();
+        P3_HIP(hipMemcpyAsync(cx.ws(stream, 0).ptr, src, bytes, hipMemcpyDeviceToDevice, stream));
+        src = cx.ws(stream, 0).as<uint32_t>();
     }
     uint32_t hinv = inverse ? bb::inv(bb::to_monty((uint32_t)height)) : 0;
     return run_dit(cx, stream, src, dst, n, width, inverse, inverse, hinv);
@@ -966,7 +954,9 @@ int ntt_coset_dft(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t
     uint32_t n = log2u(height);
     if (n > bb::TWO_ADICITY) return fail(ERR_BAD_ARG, "height exceeds BabyBear two-adicity");
     TwoLevelTable sc;
-    int rc = cx.get_scale_table(shift, n, bb::ONE, &sc);
+    int rc = cx.reserve_scale_slots(1);
+    if (rc) return rc;
+    rc = cx.get_scale_table(stream, shift, n, bb::ONE, &sc);
     if (rc) return rc;
     if (n == 0) {  // single row: scale by shift^0 = 1
         if (src != dst) P3_HIP(hipMemcpyAsync(dst, src, height * width * 4, hipMemcpyDeviceToDevice, stream));
@@ -985,6 +975,9 @@ int ntt_coset_lde(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t
     if (m > bb::TWO_ADICITY) return fail(ERR_BAD_ARG, "LDE height exceeds BabyBear two-adicity");
     if (src == dst) return fail(ERR_BAD_ARG, "coset_lde: in-place not supported");
     size_t bytes = height * width * 4;
+    // room for every scale table this call may fetch (one per coset of the narrow plan): the bounded cache is only
+    // ever emptied here, before any pointer into it is taken
+    { int rcs = cx.reserve_scale_slots(8); if (rcs) return rcs; }
     // Narrow matrices (the fib_air trace / quotient): two digits per direction, three launches.
     {
         int rcn = lde_narrow(cx, stream, src, dst, n, added_bits, width, shift, bit_reversed_out);
@@ -996,9 +989,9 @@ int ntt_coset_lde(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t
         if (rcf != 1) return rcf;  // 0 = done, <0 = error, 1 = shape not covered: separate transforms below
     }
     // 1. coefficients (natural order) into scratch: inverse DIT, 1/N folded into the scale table below
-    int rc = cx.ws[1].reserve(bytes);
+    int rc = cx.ws(stream, 1).reserve(bytes);
     if (rc) return rc;
-    uint32_t* coeffs = cx.ws[1].as<uint32_t>();
+    uint32_t* coeffs = cx.ws(stream, 1).as<uint32_t>();
     if (n == 0) P3_HIP(hipMemcpyAsync(coeffs, src, bytes, hipMemcpyDeviceToDevice, stream));
     else {
         rc = run_dit(cx, stream, src, coeffs, n, width, true, false, 0);
@@ -1011,7 +1004,7 @@ int ntt_coset_lde(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t
     // 2. forward DIF over 2^m rows: rows >= height are zero, row j scaled by shift^j / N
     TwoLevelTable sc;
     uint32_t hinv = bb::inv(bb::to_monty((uint32_t)height));
-    rc = cx.get_scale_table(shift, n, hinv, &sc);
+    rc = cx.get_scale_table(stream, shift, n, hinv, &sc);
     if (rc) return rc;
     return run_dif(cx, stream, coeffs, height, dst, m, width, false, &sc, shift, !bit_reversed_out);
 }

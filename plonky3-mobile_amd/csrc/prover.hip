@@ -364,6 +364,7 @@ static void put_words(std::vector<uint8_t>& b, const uint32_t* w, size_t n) {
 
 struct FibProver::Impl {
     int hash = HASH_POSEIDON2;
+    int device = -1;  // the arena's device: prove() refuses to run with another one current
     uint32_t log_n = 0, log_big = 0;
     FriParams fp{};
     hipStream_t stream = nullptr;
@@ -400,9 +401,11 @@ FibProver::FibProver() : im(new Impl()) {}
 FibProver::~FibProver() { delete im; }
 
 int FibProver::init(uint32_t log_n, const FriParams& fp, hipStream_t stream, bool own_stream, int hash) {
+    Impl& s = *im;
+    s.stream = stream; s.own_stream = own_stream;  // first: an owned stream is destroyed with the prover even when init fails
     if (hash != HASH_POSEIDON2 && hash != HASH_KECCAK) return fail(ERR_BAD_ARG, "fib prover: unknown hash configuration");
     im->hash = hash;
-    Impl& s = *im;
+    P3_HIP(hipGetDevice(&s.device));
     if (log_n < 1) return fail(ERR_BAD_ARG, "fib prover: log_n must be >= 1");
     if (log_n + fp.log_blowup > bb::TWO_ADICITY || log_n + fp.log_blowup > 31)
         return fail(ERR_BAD_ARG, "fib prover: LDE height exceeds two-adicity");
@@ -412,7 +415,6 @@ int FibProver::init(uint32_t log_n, const FriParams& fp, hipStream_t stream, boo
         return fail(ERR_BAD_ARG, "fib prover: log_final_poly_len must be below the trace's log height");
     if (fp.proof_of_work_bits > 30) return fail(ERR_BAD_ARG, "fib prover: proof_of_work_bits too large");
     s.log_n = log_n; s.fp = fp; s.log_big = log_n + fp.log_blowup;
-    s.stream = stream; s.own_stream = own_stream;
     const size_t n = (size_t)1 << log_n, big = (size_t)1 << s.log_big;
     int rc;
     if ((rc = s.alloc(&s.trace, n * 2))) return rc;
@@ -461,26 +463,29 @@ int FibProver::init(uint32_t log_n, const FriParams& fp, hipStream_t stream, boo
     return OK;
 }
 
-// Cached per context: selector table for log_n.
+// Cached per context: selector table for log_n (built by a kernel on `stream`; other streams wait for its event).
 static int get_selectors(Context& cx, hipStream_t stream, uint32_t log_n, const uint2** out) {
-    static thread_local std::map<uint32_t, uint2*> cache;
-    auto it = cache.find(log_n);
-    if (it != cache.end()) { *out = it->second; return OK; }
-    const uint32_t n = 1u << log_n;
-    uint2* sel = nullptr;
-    P3_HIP(hipMalloc(reinterpret_cast<void**>(&sel), (size_t)n * 8));
-    TwoLevelTable roots;
-    int rc = cx.get_root_table(log_n, false, &roots);
+    auto it = cx.selector_tables.find(log_n);
+    if (it == cx.selector_tables.end()) {
+        const uint32_t n = 1u << log_n;
+        CachedTable e;
+        P3_HIP(hipMalloc(reinterpret_cast<void**>(&e.t.lo), (size_t)n * 8));
+        TwoLevelTable roots;
+        int rc = cx.get_root_table(stream, log_n, false, &roots);
+        if (rc) { (void)hipFree(e.t.lo); return rc; }
+        uint32_t gen = bb::to_monty(bb::GEN);
+        uint32_t g = bb::two_adic_generator(log_n), ginv = bb::inv(g);
+        uint32_t zh = bb::sub(bb::pow(gen, n), bb::ONE);
+        uint32_t threads = (n + SEL_CHUNK - 1) / SEL_CHUNK;
+        hipLaunchKernelGGL(selectors_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, roots, n, gen, ginv, zh,
+                           reinterpret_cast<uint2*>(e.t.lo));
+        P3_HIP(hipGetLastError());
+        if ((rc = cx.mark_built(stream, e))) return rc;
+        it = cx.selector_tables.emplace(log_n, e).first;
+    }
+    int rc = cx.wait_ready(stream, it->second);
     if (rc) return rc;
-    uint32_t gen = bb::to_monty(bb::GEN);
-    uint32_t g = bb::two_adic_generator(log_n), ginv = bb::inv(g);
-    uint32_t zh = bb::sub(bb::pow(gen, n), bb::ONE);
-    uint32_t threads = (n + SEL_CHUNK - 1) / SEL_CHUNK;
-    hipLaunchKernelGGL(selectors_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, roots, n, gen, ginv, zh, sel);
-    P3_HIP(hipGetLastError());
-    P3_HIP(hipStreamSynchronize(stream));  // one-time: other streams of this thread may use the table next
-    cache[log_n] = sel;
-    *out = sel;
+    *out = reinterpret_cast<const uint2*>(it->second.t.lo);
     return OK;
 }
 
@@ -495,6 +500,8 @@ int FibProver::prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof) {
     int rc = get_context(&cxp);
     if (rc) return rc;
     Context& cx = *cxp;
+    if (cx.device != s.device)
+        return fail(ERR_BAD_ARG, "fib prover: created on device " + std::to_string(s.device) + ", current device is " + std::to_string(cx.device));
     hipStream_t st = s.stream;
     const uint32_t log_n = s.log_n, log_big = s.log_big;
     const uint32_t n = 1u << log_n, big = 1u << log_big;
@@ -534,7 +541,7 @@ int FibProver::prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof) {
         qa.lde = reinterpret_cast<const uint2*>(s.lde_t);
         qa.sel = sel;
         qa.out = s.qflat;
-        if ((rc = cx.get_root_table(log_n, false, &qa.roots))) return rc;
+        if ((rc = cx.get_root_table(st, log_n, false, &qa.roots))) return rc;
         qa.n = n; qa.log_n = log_n; qa.gen = gen; qa.ginv = g_n_inv;
         qa.zh_inv = bb::inv(bb::sub(bb::pow(gen, n), bb::ONE));
         memcpy(qa.pis, pis, 12);
@@ -558,7 +565,7 @@ int FibProver::prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof) {
 
     // ---- pcs.open: opened values ----
     TwoLevelTable roots_big;
-    if ((rc = cx.get_root_table(log_big, false, &roots_big))) return rc;
+    if ((rc = cx.get_root_table(st, log_big, false, &roots_big))) return rc;
     {
         uint32_t threads = (big + DEN_CHUNK - 1) / DEN_CHUNK;
         hipLaunchKernelGGL(inv_denoms_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, roots_big, big, log_big, gen,
@@ -623,7 +630,7 @@ int FibProver::prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof) {
         Ext beta = ch.sample_ext();
         TwoLevelTable inv_roots;
         uint32_t log_half = log_big - 1 - r;
-        if ((rc = cx.get_root_table(log_half + 1, true, &inv_roots))) return rc;
+        if ((rc = cx.get_root_table(st, log_half + 1, true, &inv_roots))) return rc;
         hipLaunchKernelGGL(fri_fold_kernel, dim3((half + 255) / 256), dim3(256), 0, st, inv_roots,
                            s.fri_vec + s.fri_vec_off[r], s.fri_vec + s.fri_vec_off[r + 1], half, log_half,
                            bb::scale(beta, one_half), one_half);

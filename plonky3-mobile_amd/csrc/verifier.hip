@@ -57,6 +57,11 @@ int verify_fib_air(const uint8_t* proof, size_t len, uint64_t a_pub, uint64_t b_
                    const FriParams& fp, std::string* why, int hash) {
     if (hash != HASH_POSEIDON2 && hash != HASH_KECCAK) { if (why) *why = "unknown hash configuration"; return -1; }
     auto reject = [&](int code, const char* msg) { if (why) *why = msg; return code; };
+    // the same parameter gates as FibProver::init: nothing below may shift by >= 32 or leave the two-adic subgroup
+    if (log_n < 1 || fp.log_blowup < 1 || log_n + fp.log_blowup > bb::TWO_ADICITY) return reject(-1, "bad parameters: LDE height outside [2^2, 2^27]");
+    if (fp.log_final_poly_len >= log_n && !(fp.log_final_poly_len == 0 && log_n >= 1)) return reject(-1, "bad parameters: log_final_poly_len must be below the trace's log height");
+    if (fp.proof_of_work_bits > 30) return reject(-1, "bad parameters: proof_of_work_bits too large");
+    if (fp.num_queries == 0) return reject(-1, "bad parameters: num_queries must be positive");
     Reader rd{proof, len};
     const uint32_t log_big = log_n + fp.log_blowup;
     const uint64_t n = 1ull << log_n;

@@ -235,3 +235,64 @@ def test_raw_u32_plan_entry_like_the_reference_benchmark(p3, oracle):
         assert np.array_equal(got.reshape(h, w), oracle.dft_batch(np.asarray(x, dtype=np.uint32).reshape(h, w)))
     with pytest.raises(ValueError):
         p3.plan.setup_pipeline_plan(p3.plan.prepare_compute_plan(4, 8, 0, 3), np.zeros(5, dtype=np.uint32))
+
+
+def test_two_streams_one_thread_interleaved_lde(dft, oracle, p3):
+    """include/p3hip.h stream contract: one host thread, two streams, interleaved `_dev` LDEs on different inputs.
+    Scratch is keyed by (thread, stream), so neither transform's intermediate is touched by the other."""
+    import torch
+    rng = np.random.default_rng(41)
+    cases = [(16, 2, 1), (17, 2, 1), (16, 4, 2), (12, 6, 1)]  # narrow plan (3 launches, scratch T) and general plans
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for log_h, w, ab in cases:
+        xa, xb = _rand(rng, 1 << log_h, w), _rand(rng, 1 << log_h, w)
+        da, db = p3.dev_u32(xa), p3.dev_u32(xb)
+        torch.cuda.synchronize()
+        outs = []
+        for rep in range(4):  # alternate the two streams call by call; nothing synchronises in between
+            with torch.cuda.stream(s1):
+                oa = dft.coset_lde_batch(da, ab, p3.GENERATOR_MONTY, bit_reversed_out=True)
+            with torch.cuda.stream(s2):
+                ob = dft.coset_lde_batch(db, ab, p3.MONTY_ONE, bit_reversed_out=True)
+            outs.append((oa, ob))
+        torch.cuda.synchronize()
+        ea = oracle.coset_lde_batch(xa, ab, p3.GENERATOR_MONTY, True)
+        eb = oracle.coset_lde_batch(xb, ab, p3.MONTY_ONE, True)
+        for oa, ob in outs:
+            assert np.array_equal(p3.host_u32(oa), ea), (log_h, w, ab)
+            assert np.array_equal(p3.host_u32(ob), eb), (log_h, w, ab)
+
+
+def test_scale_table_cache_cycling(dft, oracle, p3):
+    """More distinct (shift, height) pairs on one thread than the bounded table cache holds (256 entries), then a
+    blowup-8 narrow LDE (8 scale tables fetched in one call) against the oracle: the cache is only ever emptied at
+    the top of a call, never between two fetches."""
+    import torch
+    rng = np.random.default_rng(43)
+    x16 = p3.dev_u32(_rand(rng, 1 << 16, 2))
+    x12 = p3.dev_u32(_rand(rng, 1 << 12, 2))
+    for k in range(300):
+        shift = int(oracle.to_monty(np.array([3 + k], dtype=np.uint64))[0])
+        dft.coset_lde_batch(x16 if k % 2 else x12, 1, shift, bit_reversed_out=True)
+    xh = _rand(rng, 1 << 16, 2)
+    shift = int(rng.integers(1, P))
+    got = dft.coset_lde_batch(p3.dev_u32(xh), 3, shift, bit_reversed_out=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(p3.host_u32(got), oracle.coset_lde_batch(xh, 3, shift, True))
+    # and once more straight after the cache has been refilled past its cap again
+    for k in range(260):
+        dft.coset_lde_batch(x12, 1, int(oracle.to_monty(np.array([1000 + k], dtype=np.uint64))[0]), bit_reversed_out=True)
+    got = dft.coset_lde_batch(p3.dev_u32(xh), 3, shift, bit_reversed_out=True)
+    assert np.array_equal(p3.host_u32(got), oracle.coset_lde_batch(xh, 3, shift, True))
+
+
+def test_release_thread_context_and_reuse(dft, oracle, p3):
+    """p3hip_release_thread_context frees the thread's tables and scratch; the next call rebuilds them."""
+    from plonky3_mobile_amd import _lib
+    rng = np.random.default_rng(47)
+    x = _rand(rng, 1 << 10, 3)
+    exp = oracle.dft_batch(x)
+    assert np.array_equal(dft.dft_batch(x), exp)
+    _lib.lib().p3hip_release_thread_context()
+    assert np.array_equal(dft.dft_batch(x), exp)
+    assert np.array_equal(p3.host_u32(dft.dft_batch(p3.dev_u32(x))), exp)

@@ -69,9 +69,10 @@ class _Worker(threading.Thread):
 
 
 class FibAirJob:
-    def __init__(self, p3, log_height, log_blowup, batch, first_instance=0, threads=4, hash="poseidon2"):
+    def __init__(self, p3, log_height, log_blowup, batch, first_instance=0, threads=4, hash="poseidon2", config_label=None):
         self.p3 = p3
         self.hash = hash
+        self.config_label = config_label  # "configs[1]" / "configs[2]" when the size IS that BASELINE config
         self.device = torch.cuda.current_device()
         self.log_height, self.log_blowup, self.batch = log_height, log_blowup, batch
         self.first = first_instance
@@ -100,8 +101,74 @@ class FibAirJob:
         if self.hash == "keccak":
             return ("fib_air 2^%d-row trace, BabyBear + the reference's own Keccak hashes (fib_air.rs:28-53, non-hiding), "
                     "blowup %d" % (self.log_height, 1 << self.log_blowup))
-        return "fib_air 2^%d-row trace, BabyBear+Poseidon2, blowup %d (BASELINE configs[1])" % (
-            self.log_height, 1 << self.log_blowup)
+        return "fib_air 2^%d-row trace, BabyBear+Poseidon2, blowup %d%s" % (
+            self.log_height, 1 << self.log_blowup, " (BASELINE %s)" % self.config_label if self.config_label else "")
+
+    def config(self):
+        return {"log_height": self.log_height, "width": 2, "log_blowup": self.log_blowup, "batch_per_gpu": self.batch,
+                "concurrent_provers_per_gpu": self.threads,
+                "fri": {"log_final_poly_len": self.params.log_final_poly_len, "num_queries": self.params.num_queries,
+                        "proof_of_work_bits": self.params.proof_of_work_bits}}
+
+    def roofline(self):
+        """The dominant HBM-bound unit of a proof: the coset LDE (HIP events on the launch stream; algorithmic bytes
+        4*h*w*(1+blowup)); `traffic` from the committed PMC passes of the same unit."""
+        import json
+        roof = self.lde_roofline(reps=20)
+        traffic, src = None, None
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        for name in ("r02_pmc_lde.json", "r01_pmc_lde_v2.json"):
+            try:
+                with open(os.path.join(root, "profiles", name)) as f:
+                    pmc = json.load(f)
+                key = {(20, 1): "cfg2_lde_2^20x2_blowup2", (24, 2): "cfg3_lde_2^24x2_blowup4"}.get((self.log_height, self.log_blowup))
+                if key and key in pmc:
+                    traffic = pmc[key]["total_bytes"]
+                    src = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, summed over "
+                           "the unit's launches (tools/pmc_probe.py, tools/pmc_summarize.py)" % name)
+                    break
+            except Exception:
+                continue
+        return {"bound": "hbm", "achieved": roof["gbps"], "peak": 8000.0, "unit": "GB/s", "frac": roof["gbps"] / 8000.0,
+                "frac_of_achievable_6300": roof["gbps"] / 6300.0, "traffic": traffic, "traffic_source": src,
+                "kernel": "coset_lde_batch (narrow plan: one unit of " + str(roof.get("launches", "3")) + " launches)",
+                "algorithmic_bytes": roof["bytes"], "avg_us": roof["avg_us"],
+                "concurrent_gbps": roof.get("concurrent_gbps"), "concurrent_streams": roof.get("concurrent_streams")}
+
+    def extra_report(self):
+        return {"valu_roofline": self.poseidon2_roofline(), "stages_ms": self.stage_breakdown()}
+
+    def poseidon2_roofline(self):
+        """The kernels that dominate a proof BY TIME are the Poseidon2 leaf / compression layers (12.6 M permutations per
+        2^20 proof) and they are VALU-bound, which the contract's hbm|mfma roofline cannot express.  achieved = the rate of
+        the kernels the prover really runs (a 2^21 x 2 commit: leaf_hash_f64 + compress_layer_f64 + the small layers);
+        the ceiling is NOT a model: `frac` = VALU-busy cycles / elapsed cycles of those kernels from the committed PMC
+        pass (profiles/r02_pmc_poseidon2.json), so it is <= 1 by construction."""
+        import json
+        n = self.n << self.log_blowup
+        x = torch.randint(0, 0x78000001, (n, 2), dtype=torch.int32, device="cuda")
+
+        def commit():
+            _, t = self.mmcs.commit([x])
+            t.free()
+        ms = self._time(commit, 5)
+        perms = 2 * n - 1
+        out = {"kernel": "Poseidon2 leaf/compress layers as the prover runs them (commit of 2^%d x 2: leaf_hash_f64_kernel, "
+                         "compress_layer_f64_kernel, tree_levels_coop_kernel)" % (self.log_height + self.log_blowup),
+               "achieved": perms / (ms * 1e-3) / 1e9, "unit": "Gperm/s", "permutations": perms, "avg_us": ms * 1e3,
+               "raw_permute_kernel_gperm_s": self.poseidon2_rate() / 1e9}
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        try:
+            with open(os.path.join(root, "profiles", "r02_pmc_poseidon2.json")) as f:
+                pmc = json.load(f)
+            out["frac"] = pmc["summary"]["valu_busy_frac"]
+            out["bound"] = "valu"
+            out["frac_source"] = "profiles/r02_pmc_poseidon2.json (" + pmc["summary"]["definition"] + ")"
+            out["instructions_per_permutation"] = pmc["summary"].get("valu_insts_per_permutation")
+        except Exception:
+            out["frac"] = None
+            out["frac_source"] = "profiles/r02_pmc_poseidon2.json missing: no counter evidence committed yet"
+        return out
 
     def step(self, instances=None):
         """Proves independent instances; default: (a, b) = (first+i, first+i+1) for i < batch.
@@ -226,3 +293,77 @@ class FibAirJob:
         w.inbox.put(("stages", None))
         out.update(w.result())  # single-proof latency split, host wall clock
         return out
+
+
+class WideCommitJob:
+    """BASELINE configs[4]: the wide trace 2^16 x 2633 (the reference's benchmark_input, fib_air.rs:77-86, standing in
+    for the Keccak-f AIR trace), bit-reversed coset LDE at blowup 2 + MMCS commit of the 2^17-row result.
+    step() = one LDE + one commit on the current stream, inputs resident in HBM."""
+
+    def __init__(self, p3, log_height=16, log_blowup=1, width=2633, hash="poseidon2"):
+        from .fib_air import benchmark_input
+        from .gpu_dft import dev_u32
+        self.p3, self.hash = p3, hash
+        self.log_height, self.log_blowup, self.width = log_height, log_blowup, width
+        self.h = 1 << log_height
+        self.dft = GpuDft.with_backend(BackendKind.Hip)
+        self.mmcs = MerkleTreeMmcs(hash)
+        self.host_x = benchmark_input(self.h, width)
+        self.x = dev_u32(self.host_x)
+        self.lde = torch.empty((self.h << log_blowup, width), dtype=torch.int32, device="cuda")
+        self.batch = 1
+        self.threads = 1
+        self.last_root = None
+        torch.cuda.synchronize()
+
+    def close(self):
+        pass
+
+    def metric_name(self):
+        return "wide-trace coset LDE + MMCS commits/sec"
+
+    def unit(self):
+        return "commits/s"
+
+    def workload_name(self):
+        return "2^%d x %d trace (benchmark_input), blowup %d, bit-reversed coset LDE + %s MMCS commit (BASELINE configs[4])" % (
+            self.log_height, self.width, 1 << self.log_blowup, "Poseidon2" if self.hash == "poseidon2" else "Keccak")
+
+    def config(self):
+        return {"log_height": self.log_height, "width": self.width, "log_blowup": self.log_blowup, "batch_per_gpu": 1}
+
+    def _lde(self):
+        L = _lib.lib()
+        _lib.check(L.p3hip_coset_lde_batch_bb31_dev(C.c_void_p(self.x.data_ptr()), C.c_void_p(self.lde.data_ptr()), self.h,
+                                                    self.width, self.log_blowup, GENERATOR_MONTY, 1, _stream_ptr()))
+
+    def _commit(self):
+        root, t = self.mmcs.commit([self.lde])
+        t.free()
+        return root
+
+    def step(self, instances=None):
+        self._lde()
+        self.last_root = self._commit()
+        return self.last_root
+
+    _time = FibAirJob._time
+
+    def roofline(self):
+        H = self.h << self.log_blowup
+        lde_bytes = 4 * self.h * self.width * (1 + (1 << self.log_blowup))
+        commit_bytes = 4 * H * self.width + 32 * (2 * H - 1)
+        t_lde = self._time(self._lde, 10)
+        t_commit = self._time(self._commit, 10)
+        perms = H * ((self.width + 7) // 8) + H - 1 if self.hash == "poseidon2" else H * ((((self.width + 1) // 2) + 16) // 17) + H - 1
+        return {"bound": "hbm", "kernel": "coset_lde_batch of the wide matrix (general plans: ntt_fast kernels)",
+                "achieved": lde_bytes / (t_lde * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                "frac": lde_bytes / (t_lde * 1e-3) / 1e9 / 8000.0,
+                "frac_of_achievable_6300": lde_bytes / (t_lde * 1e-3) / 1e9 / 6300.0,
+                "algorithmic_bytes": lde_bytes, "avg_us": t_lde * 1e3, "traffic": None,
+                "commit": {"bound": "valu (hash)", "algorithmic_bytes": commit_bytes, "avg_us": t_commit * 1e3,
+                           "achieved_gbps": commit_bytes / (t_commit * 1e-3) / 1e9, "permutations": perms,
+                           "gperm_s": perms / (t_commit * 1e-3) / 1e9}}
+
+    def extra_report(self):
+        return {}

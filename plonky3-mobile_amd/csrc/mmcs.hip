@@ -507,7 +507,9 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
     }
     // Layers with fewer than COOP_MAX permutations cannot fill the chip with one state per lane: they run the
     // 16-lanes-per-state kernels (latency ~6x lower); the last <= 1024 digests finish inside one workgroup.
-    const uint64_t COOP_MAX = 1u << 15;
+    // P3HIP_COOP_MAX_LOG: 15 minimises a single tree's latency; lower values spend fewer lane-instructions (the
+    // 16-lane form costs ~3.4x the VALU work of a one-state-per-lane permutation) when other work fills the chip
+    static const uint64_t COOP_MAX = [] { const char* e = getenv("P3HIP_COOP_MAX_LOG"); int v = e ? atoi(e) : 15; return (uint64_t)1 << (v < 7 ? 7 : (v > 15 ? 15 : v)); }();
     if (kind == HASH_KECCAK) {
         // one state per lane for every layer (no lane-cooperative form: the 64-bit lanes do not split over DPP rows)
         RowSet rs0 = make_rowset(*t, maxh);

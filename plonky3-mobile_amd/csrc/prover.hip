@@ -23,6 +23,7 @@
 #include "poseidon2.cuh"
 #include "poseidon2_f64.cuh"
 #include "prover.h"
+#include "transcript.cuh"
 
 namespace p3 {
 
@@ -74,34 +75,35 @@ __global__ void selectors_kernel(TwoLevelTable roots, uint32_t n, uint32_t gen, 
         if (i0 + k < n) sel[i0 + k] = make_uint2(v[2 * k], v[2 * k + 1]);
 }
 
-// quotient_values for FibonacciAir (fib_air.rs:232-264), natural order out (n x 4 base words).
+// quotient_values for FibonacciAir (fib_air.rs:232-264), natural order out (n x 4 base words).  The public values and
+// the powers of alpha come from the device transcript.
 struct QuotArgs {
     const uint2* lde;   // committed trace LDE, bit-reversed rows; first n rows = the quotient domain
     const uint2* sel;
     uint32_t* out;
+    const DevState* ds;
     TwoLevelTable roots;  // w_n^i
     uint32_t n, log_n, gen, ginv, zh_inv;
-    uint32_t pis[3];
-    Ext apow[5];          // alpha^0..alpha^4
 };
 __global__ void __launch_bounds__(256) fib_quotient_kernel(QuotArgs a) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
+    const DevState* __restrict__ ds = a.ds;
     uint2 loc = a.lde[brev(i, a.log_n)];
     uint2 nxt = a.lde[brev((i + 1) & (a.n - 1), a.log_n)];
     uint2 s = a.sel[i];
     uint32_t x = bb::mul(a.gen, tl(a.roots, i));
     uint32_t trans = bb::sub(x, a.ginv);
-    uint32_t c0 = bb::mul(s.x, bb::sub(loc.x, a.pis[0]));
-    uint32_t c1 = bb::mul(s.x, bb::sub(loc.y, a.pis[1]));
+    uint32_t c0 = bb::mul(s.x, bb::sub(loc.x, ds->pis[0]));
+    uint32_t c1 = bb::mul(s.x, bb::sub(loc.y, ds->pis[1]));
     uint32_t c2 = bb::mul(trans, bb::sub(loc.y, nxt.x));
     uint32_t c3 = bb::mul(trans, bb::sub(bb::add(loc.x, loc.y), nxt.y));
-    uint32_t c4 = bb::mul(s.y, bb::sub(loc.y, a.pis[2]));
-    Ext acc = bb::scale(a.apow[4], c0);
-    acc = bb::add(acc, bb::scale(a.apow[3], c1));
-    acc = bb::add(acc, bb::scale(a.apow[2], c2));
-    acc = bb::add(acc, bb::scale(a.apow[1], c3));
-    acc = bb::add(acc, bb::scale(a.apow[0], c4));
+    uint32_t c4 = bb::mul(s.y, bb::sub(loc.y, ds->pis[2]));
+    Ext acc = bb::scale(ds->apow[4], c0);
+    acc = bb::add(acc, bb::scale(ds->apow[3], c1));
+    acc = bb::add(acc, bb::scale(ds->apow[2], c2));
+    acc = bb::add(acc, bb::scale(ds->apow[1], c3));
+    acc = bb::add(acc, bb::scale(ds->apow[0], c4));
     st_ext(a.out + 4 * (size_t)i, bb::scale(acc, a.zh_inv));
 }
 
@@ -112,26 +114,10 @@ __global__ void __launch_bounds__(256) fib_quotient_kernel(QuotArgs a) {
 // Y B^2 is a constant of the point z; A^2 - Y B^2 = (a0^2 + k0) + (k1 a0 - c1) Y =: d0 + d1 Y; its inverse is
 // (d0 - d1 Y) / (d0^2 - 11 d1^2), and those BASE-FIELD norms are batch-inverted per lane (Montgomery's trick).
 // 24 base products per inverse instead of the 57 of a batched quartic-extension inversion; same field elements.
-struct DenConsts {  // for one point z = (z0, z1, z2, z3)
-    uint32_t z0, z1, z2, z3, k0, k1, c1, z2w, z3w;
-};
-static DenConsts den_consts(const Ext& z) {
-    DenConsts k{};
-    k.z0 = z.c[0]; k.z1 = z.c[1]; k.z2 = z.c[2]; k.z3 = z.c[3];
-    const uint32_t W = bb::W_MONTY;
-    // B^2 = (z1^2 + W z3^2) + 2 z1 z3 Y;  Y B^2 = W * 2 z1 z3 + (z1^2 + W z3^2) Y = c0 + c1 Y
-    uint32_t b0 = bb::add(bb::sqr(z.c[1]), bb::mul(W, bb::sqr(z.c[3]))), b1 = bb::dbl(bb::mul(z.c[1], z.c[3]));
-    uint32_t c0 = bb::mul(W, b1);
-    k.c1 = b0;
-    k.k0 = bb::sub(bb::mul(W, bb::sqr(z.c[2])), c0);  // A^2 = (a0^2 + W z2^2) + 2 a0 z2 Y
-    k.k1 = bb::dbl(z.c[2]);
-    k.z2w = bb::mul(W, z.c[2]);
-    k.z3w = bb::mul(W, z.c[3]);
-    return k;
-}
 constexpr int DEN_CHUNK = 4;
 __global__ void __launch_bounds__(256) inv_denoms_kernel(TwoLevelTable roots, uint32_t big, uint32_t log_big, uint32_t gen,
-                                                         DenConsts k0, DenConsts k1, uint32_t* d0, uint32_t* d1) {
+                                                         const DevState* __restrict__ ds, uint32_t* d0, uint32_t* d1) {
+    const DenConsts k0 = ds->k0, k1 = ds->k1;  // constants of zeta and zeta * g from the device transcript
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t j0 = t * DEN_CHUNK;
     if (j0 >= big) return;
@@ -234,33 +220,34 @@ struct ReducedArgs {
     const uint32_t* d0;
     const uint32_t* d1;
     uint32_t* ro;
+    const DevState* ds;  // alp[0..8), y02 = ry0 + alpha^4 ry2, y1 = alpha^2 ry1
     uint32_t big;
-    Ext alp[8];   // alpha^0..alpha^7
-    Ext y02, y1;  // ry0 + alpha^4 ry2, alpha^2 ry1
 };
 __global__ void __launch_bounds__(256) reduced_openings_kernel(ReducedArgs a) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= a.big) return;
+    const DevState* __restrict__ ds = a.ds;
     uint2 t = a.lde_t[j];
     uint4 q = a.lde_q[j];
-    Ext u = bb::scale(a.alp[1], t.y);  // rt
+    Ext u = bb::scale(ds->alp[1], t.y);  // rt
     u.c[0] = bb::add(u.c[0], t.x);
-    u = bb::add(u, bb::scale(a.alp[4], q.x));
-    u = bb::add(u, bb::scale(a.alp[5], q.y));
-    u = bb::add(u, bb::scale(a.alp[6], q.z));
-    u = bb::add(u, bb::scale(a.alp[7], q.w));
-    Ext w = bb::add(bb::scale(a.alp[2], t.x), bb::scale(a.alp[3], t.y));  // alpha^2 rt
+    u = bb::add(u, bb::scale(ds->alp[4], q.x));
+    u = bb::add(u, bb::scale(ds->alp[5], q.y));
+    u = bb::add(u, bb::scale(ds->alp[6], q.z));
+    u = bb::add(u, bb::scale(ds->alp[7], q.w));
+    Ext w = bb::add(bb::scale(ds->alp[2], t.x), bb::scale(ds->alp[3], t.y));  // alpha^2 rt
     Ext e0 = ld_ext(a.d0 + 4 * (size_t)j), e1 = ld_ext(a.d1 + 4 * (size_t)j);
-    Ext r = bb::add(bb::mul(bb::sub(a.y02, u), e0), bb::mul(bb::sub(a.y1, w), e1));
+    Ext r = bb::add(bb::mul(bb::sub(ds->y02, u), e0), bb::mul(bb::sub(ds->y1, w), e1));
     st_ext(a.ro + 4 * (size_t)j, r);
 }
 
-// TwoAdicFriFolding::fold_matrix: out[i] = (lo + hi)/2 + (beta/2) g^-bitrev(i) (lo - hi)
+// TwoAdicFriFolding::fold_matrix: out[i] = (lo + hi)/2 + (beta/2) g^-bitrev(i) (lo - hi); beta/2 from the transcript
 __global__ void __launch_bounds__(256) fri_fold_kernel(TwoLevelTable inv_roots /* w_len^-e */, const uint32_t* in,
-                                                       uint32_t* out, uint32_t half, uint32_t log_half, Ext half_beta,
-                                                       uint32_t one_half) {
+                                                       uint32_t* out, uint32_t half, uint32_t log_half,
+                                                       const DevState* __restrict__ ds, uint32_t round, uint32_t one_half) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= half) return;
+    const Ext half_beta = ds->half_beta[round];
     Ext lo = ld_ext(in + 8 * (size_t)i), hi = ld_ext(in + 8 * (size_t)i + 4);
     uint32_t p = tl(inv_roots, brev(i, log_half));
     Ext s = bb::scale(bb::add(lo, hi), one_half);
@@ -268,34 +255,33 @@ __global__ void __launch_bounds__(256) fri_fold_kernel(TwoLevelTable inv_roots /
     st_ext(out + 4 * (size_t)i, bb::add(s, d));
 }
 
-// GrindingChallenger::grind: smallest canonical w with sample_bits(bits) == 0 after observe(w).
-__global__ void __launch_bounds__(256) grind_kernel(const uint32_t* state16, uint32_t pos, uint32_t mask, uint32_t base,
-                                                    uint32_t* result) {
+// GrindingChallenger::grind: smallest canonical w with sample_bits(bits) == 0 after observe(w).  The sponge state
+// with the pending inputs comes from the device transcript; blocks whose whole range lies above a witness already
+// found return at once (the smallest one wins through atomicMin, as in a serial search).
+__global__ void __launch_bounds__(256) grind_kernel(DevState* ds, uint32_t mask, uint32_t base) {
     uint32_t w = base + blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= bb::P) return;
+    if (base + blockIdx.x * blockDim.x > *(volatile uint32_t*)&ds->grind_result) return;
     // fp64 form of the permutation (poseidon2_f64.cuh: canonical values in doubles), as in the tree kernels
+    const uint32_t pos = ds->n_in;  // the witness is the next observed element
     double s[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) s[i] = p2f::load_elem(state16[i]);
+    for (int i = 0; i < 16; i++) s[i] = p2f::load_elem((i < 8 && (uint32_t)i < pos) ? ds->inb[i & 7] : ds->st[i]);
 #pragma unroll
     for (int i = 0; i < 8; i++) s[i] = (i == (int)pos) ? (double)w : s[i];
     p2f::permute(s);
-    if ((bb::from_monty(p2f::store_elem(s[7])) & mask) == 0) atomicMin(result, w);
+    if ((bb::from_monty(p2f::store_elem(s[7])) & mask) == 0) atomicMin(&ds->grind_result, w);
 }
 
 // The same search for the Keccak-256 HashChallenger: candidate w is observed as the 4 little-endian bytes of its
-// Montgomery word after the pending input bytes; the host has absorbed the complete 136-byte blocks already and
-// hands over the state plus up to two template blocks (pending tail bytes, zeroed witness bytes, 0x01 / 0x80
-// padding).  sample_bits pops digest bytes from the back, four per try, masks to 31 bits and retries while >= P.
-struct KeccakGrindArgs {
-    uint64_t state[25];
-    uint64_t block[2][17];
-    uint32_t n_blocks, wpos;  // witness byte offset within the template (may straddle lanes and blocks)
-    uint32_t mask, base;
-};
-__global__ void __launch_bounds__(256) grind_keccak_kernel(KeccakGrindArgs a, uint32_t* result) {
-    uint32_t w = a.base + blockIdx.x * blockDim.x + threadIdx.x;
+// Montgomery word after the pending input bytes; the transcript has absorbed the complete 136-byte blocks already and
+// hands over the state plus up to two template blocks (DevState::kgrind).  sample_bits pops digest bytes from the
+// back, four per try, masks to 31 bits and retries while >= P.
+__global__ void __launch_bounds__(256) grind_keccak_kernel(DevState* ds, uint32_t mask, uint32_t base) {
+    uint32_t w = base + blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= bb::P) return;
+    if (base + blockIdx.x * blockDim.x > *(volatile uint32_t*)&ds->grind_result) return;
+    const KeccakGrindArgs& a = ds->kgrind;
     const uint32_t wm = bb::to_monty(w);
     uint64_t st[25];
 #pragma unroll
@@ -321,9 +307,9 @@ __global__ void __launch_bounds__(256) grind_keccak_kernel(KeccakGrindArgs a, ui
         const uint64_t lane = st[3 - t / 2];
         const uint32_t hi_or_lo = (t & 1) ? (uint32_t)lane : (uint32_t)(lane >> 32);  // bytes 4k+3 .. 4k, k = 7 - t
         const uint32_t v = __builtin_bswap32(hi_or_lo) & 0x7fffffffu;                // first pop = low byte
-        if (v < bb::P) { ok = (v & a.mask) == 0; break; }
+        if (v < bb::P) { ok = (v & mask) == 0; break; }
     }
-    if (ok) atomicMin(result, w);
+    if (ok) atomicMin(&ds->grind_result, w);
 }
 
 // Batched Mmcs::open_batch for the query phase: block (q, t) copies tree t's opened row and sibling path
@@ -336,7 +322,8 @@ struct QTree {
 __global__ void query_gather_kernel(const QTree* trees, uint32_t n_trees, const uint32_t* indices, uint32_t slot_words,
                                     uint32_t* out) {
     const QTree t = trees[blockIdx.y];
-    uint64_t index = indices[blockIdx.x] >> t.shift;
+    // masked: whatever the index buffer holds, the gather stays inside the tree
+    uint64_t index = (indices[blockIdx.x] >> t.shift) & ((1ull << t.log_height) - 1ull);
     uint32_t* dst = out + (size_t)blockIdx.x * slot_words + t.slot_off;
     for (uint32_t c = threadIdx.x; c < t.width; c += blockDim.x) dst[c] = t.mat[index * t.width + c];
     uint64_t base = 0, len = 1ull << t.log_height;
@@ -346,6 +333,188 @@ __global__ void query_gather_kernel(const QTree* trees, uint32_t n_trees, const 
         base += len * 8;
         len >>= 1;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// transcript kernels: one wavefront each, between the bulk kernels, on the same stream (transcript.cuh)
+// ------------------------------------------------------------------------------------------------
+// Proof staging buffer (device words; copied to the host once per proof):
+//   root_t[8] root_q[8] opened[8][4] froots[n_rounds][8] fpoly[fpl][4] witness status qidx[nq] (pad) slots[nq][slot_words]
+struct StageLayout {
+    uint32_t root_t = 0, root_q = 8, opened = 16, froots = 48, fpoly = 0, witness = 0, status = 0, qidx = 0, slots = 0, words = 0;
+};
+struct TsArgs {
+    DevState* ds;
+    uint32_t* ps;
+    int kind;
+    StageLayout lay;
+};
+
+// observe the instance, sample alpha: p3_uni_stark::prove up to the quotient computation
+__global__ void __launch_bounds__(64) ts_begin_kernel(TsArgs a, const uint32_t* trace, uint32_t n, uint32_t log_n) {
+    __shared__ KState ks;
+    DevChal ch;
+    ch.begin(a.kind, a.ds, &ks, true);
+    const uint32_t pis[3] = {trace[0], trace[1], trace[2 * (size_t)(n - 1) + 1]};  // first row and last right value
+    ch.observe(bb::to_monty(log_n));  // log_ext_degree
+    ch.observe(bb::to_monty(log_n));  // log_degree
+    ch.observe_n(a.ps + a.lay.root_t, 8);
+    ch.observe_n(pis, 3);
+    const Ext alpha = ch.sample_ext();
+    Ext ap[5];
+    ap[0] = bb::ext_one();
+#pragma unroll
+    for (int k = 1; k < 5; k++) ap[k] = bb::mul(ap[k - 1], alpha);
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 3; k++) a.ds->pis[k] = pis[k];
+        for (int k = 0; k < 5; k++) a.ds->apow[k] = ap[k];
+        a.ds->status = 0;
+        a.ps[a.lay.status] = 0;
+    }
+    ch.end();
+}
+// observe the quotient commitment, sample zeta
+__global__ void __launch_bounds__(64) ts_zeta_kernel(TsArgs a, uint32_t g_n) {
+    __shared__ KState ks;
+    DevChal ch;
+    ch.begin(a.kind, a.ds, &ks, false);
+    ch.observe_n(a.ps + a.lay.root_q, 8);
+    const Ext zeta = ch.sample_ext();
+    const Ext zeta_next = bb::scale(zeta, g_n);
+    if (threadIdx.x == 0) {
+        a.ds->zeta = zeta;
+        a.ds->zeta_next = zeta_next;
+        a.ds->k0 = den_consts(zeta);
+        a.ds->k1 = den_consts(zeta_next);
+    }
+    ch.end();
+}
+// finish the barycentric sums into the opened values, observe them, sample the batching challenge
+constexpr int TS_OPEN_THREADS = 256;
+__global__ void __launch_bounds__(TS_OPEN_THREADS) ts_open_kernel(TsArgs a, const uint32_t* partials, uint32_t n_blocks,
+                                                                  uint32_t log_n, uint32_t sn, uint32_t denom) {
+    __shared__ KState ks;
+    __shared__ uint32_t red[TS_OPEN_THREADS / 32][32];
+    __shared__ uint32_t tot[32];
+    {
+        const uint32_t col = threadIdx.x & 31u, part = threadIdx.x >> 5;
+        uint32_t v = 0;
+        for (uint32_t b = part; b < n_blocks; b += TS_OPEN_THREADS / 32) v = bb::add(v, partials[b * 32 + col]);
+        red[part][col] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int p = 0; p < TS_OPEN_THREADS / 32; p++) v = bb::add(v, red[p][threadIdx.x]);
+        tot[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    DevChal ch;
+    ch.begin(a.kind, a.ds, &ks, false);
+    Ext opened[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) opened[k].c[c] = tot[4 * k + c];
+    {   // interpolate_coset's factor (z^n - s^n) / (n s^n) for z = zeta and zeta * g
+        Ext z0 = a.ds->zeta, z1 = a.ds->zeta_next;
+        for (uint32_t i = 0; i < log_n; i++) { z0 = bb::sqr(z0); z1 = bb::sqr(z1); }
+        const Ext f0 = bb::scale(bb::sub(z0, bb::ext_from_base(sn)), denom);
+        const Ext f1 = bb::scale(bb::sub(z1, bb::ext_from_base(sn)), denom);
+#pragma unroll
+        for (int k = 0; k < 8; k++) opened[k] = bb::mul(opened[k], (k == 2 || k == 3) ? f1 : f0);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) ch.observe_ext(opened[k]);
+    const Ext al = ch.sample_ext();
+    Ext alp[8];
+    alp[0] = bb::ext_one();
+#pragma unroll
+    for (int k = 1; k < 8; k++) alp[k] = bb::mul(alp[k - 1], al);
+    const Ext ry0 = bb::add(opened[0], bb::mul(alp[1], opened[1]));
+    const Ext ry1 = bb::add(opened[2], bb::mul(alp[1], opened[3]));
+    const Ext ry2 = bb::add(bb::add(opened[4], bb::mul(alp[1], opened[5])),
+                            bb::add(bb::mul(alp[2], opened[6]), bb::mul(alp[3], opened[7])));
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 8; k++) {
+            a.ds->alp[k] = alp[k];
+            for (int c = 0; c < 4; c++) a.ps[a.lay.opened + 4 * k + c] = opened[k].c[c];
+        }
+        a.ds->y02 = bb::add(ry0, bb::mul(alp[4], ry2));
+        a.ds->y1 = bb::mul(alp[2], ry1);
+    }
+    ch.end();
+}
+// FRI commit phase, round r: observe the layer's commitment, sample beta
+__global__ void __launch_bounds__(64) ts_fri_round_kernel(TsArgs a, uint32_t round, uint32_t one_half) {
+    __shared__ KState ks;
+    DevChal ch;
+    ch.begin(a.kind, a.ds, &ks, false);
+    ch.observe_n(a.ps + a.lay.froots + 8 * round, 8);
+    const Ext beta = ch.sample_ext();
+    if (threadIdx.x == 0) a.ds->half_beta[round] = bb::scale(beta, one_half);
+    ch.end();
+}
+// observe the final polynomial; set up the proof-of-work search
+__global__ void __launch_bounds__(64) ts_final_kernel(TsArgs a, uint32_t fpl, uint32_t pow_mask) {
+    __shared__ KState ks;
+    DevChal ch;
+    ch.begin(a.kind, a.ds, &ks, false);
+    for (uint32_t i = 0; i < 4 * fpl; i++) ch.observe(a.ps[a.lay.fpoly + i]);
+    ch.end();
+    if (threadIdx.x == 0) {
+        a.ds->grind_result = 0xffffffffu;
+        if (a.kind == HASH_KECCAK) {
+            // the sponge holds the complete blocks; the template carries the pending tail, room for the witness, padding
+            KeccakGrindArgs& g = a.ds->kgrind;
+            for (int i = 0; i < 25; i++) g.state[i] = ks.st[i];
+            uint8_t tmpl[272];
+            for (int i = 0; i < 272; i++) tmpl[i] = 0;
+            const uint32_t tail = ks.blen;
+            for (uint32_t i = 0; i < tail; i++) tmpl[i] = ks.blk[i];
+            const uint32_t end = tail + 4;  // message end within the template
+            g.n_blocks = end < 136 ? 1 : 2;
+            tmpl[end] ^= 0x01;
+            tmpl[g.n_blocks * 136 - 1] ^= 0x80;
+            for (int b = 0; b < 2; b++)
+                for (int i = 0; i < 17; i++) {
+                    uint64_t w = 0;
+                    for (int j = 0; j < 8; j++) w |= (uint64_t)tmpl[b * 136 + 8 * i + j] << (8 * j);
+                    g.block[b][i] = w;
+                }
+            g.wpos = tail;
+            g.mask = pow_mask;
+            g.base = 0;
+        }
+    }
+}
+// check the witness, observe it, sample the query indices.  If the search range held no witness the transcript is
+// left untouched and the host continues the search (status = ST_GRIND_MISS).
+__global__ void __launch_bounds__(64) ts_queries_kernel(TsArgs a, uint32_t nq, uint32_t log_big, uint32_t pow_bits, uint32_t* qidx) {
+    __shared__ KState ks;
+    const uint32_t found = a.ds->grind_result;
+    if (found == 0xffffffffu) {
+        if (threadIdx.x == 0) { a.ds->status = ST_GRIND_MISS; a.ps[a.lay.status] = ST_GRIND_MISS; }
+        for (uint32_t q = threadIdx.x; q < nq; q += 64) qidx[q] = 0;  // the gather that follows reads defined indices
+        return;
+    }
+    DevChal ch;
+    ch.begin(a.kind, a.ds, &ks, false);
+    const uint32_t witness = bb::to_monty(found);
+    ch.observe(witness);
+    const uint32_t zero_bits = ch.sample_bits(pow_bits);
+    if (threadIdx.x == 0) {
+        a.ps[a.lay.witness] = witness;
+        a.ps[a.lay.status] = zero_bits == 0 ? 0u : 2u;  // 2: the transcript rejects the witness the search returned
+        a.ds->status = 0;
+    }
+    for (uint32_t q = 0; q < nq; q++) {
+        const uint32_t idx = ch.sample_bits(log_big);
+        if (threadIdx.x == 0) { qidx[q] = idx; a.ps[a.lay.qidx + q] = idx; }
+    }
+    ch.end();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -362,6 +531,8 @@ static void put_words(std::vector<uint8_t>& b, const uint32_t* w, size_t n) {
     memcpy(b.data() + o, w, 4 * n);
 }
 
+constexpr int N_STAGE_EVENTS = 7;
+
 struct FibProver::Impl {
     int hash = HASH_POSEIDON2;
     int device = -1;  // the arena's device: prove() refuses to run with another one current
@@ -372,12 +543,12 @@ struct FibProver::Impl {
     // arena
     uint32_t *trace = nullptr, *lde_t = nullptr, *qflat = nullptr, *lde_q = nullptr, *d0 = nullptr, *d1 = nullptr;
     uint32_t *layers_t = nullptr, *layers_q = nullptr, *fri_vec = nullptr, *fri_layers = nullptr;
-    uint32_t *partials = nullptr, *small = nullptr, *qstage = nullptr, *qidx = nullptr;
+    uint32_t *partials = nullptr, *qidx = nullptr, *pstage = nullptr, *fp_ev = nullptr;
+    DevState* ds = nullptr;
     QTree* qtrees = nullptr;
-    uint32_t* host_pinned = nullptr;  // pinned staging for small D2H reads
-    uint32_t* host_roots = nullptr;   // pinned + device-mapped: tree tops write their root here directly
-    uint32_t* dev_roots = nullptr;
-    size_t host_pinned_words = 0;
+    uint32_t* host_stage = nullptr;  // pinned: the proof staging buffer lands here, one copy per proof
+    StageLayout lay;
+    hipEvent_t ev[N_STAGE_EVENTS] = {nullptr};
     std::vector<void*> allocs;
     uint32_t n_rounds = 0;
     std::vector<size_t> fri_vec_off, fri_layer_off;  // word offsets per round
@@ -386,8 +557,8 @@ struct FibProver::Impl {
     StageTimes times{};
     ~Impl() {
         for (void* p : allocs) (void)hipFree(p);
-        if (host_pinned) (void)hipHostFree(host_pinned);
-        if (host_roots) (void)hipHostFree(host_roots);
+        if (host_stage) (void)hipHostFree(host_stage);
+        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
     int alloc(uint32_t** p, size_t words) {
@@ -427,6 +598,7 @@ int FibProver::init(uint32_t log_n, const FriParams& fp, hipStream_t stream, boo
     if ((rc = s.alloc(&s.layers_q, mmcs_layer_words(big)))) return rc;
     // FRI: vector r has big >> r ext elements; its commitment tree has (big >> (r+1)) leaves
     s.n_rounds = s.log_big - fp.log_blowup - fp.log_final_poly_len;
+    if (s.n_rounds > MAX_FRI_ROUNDS) return fail(ERR_BAD_ARG, "fib prover: too many FRI rounds");
     size_t vec_words = 0, layer_words = 0;
     for (uint32_t r = 0; r <= s.n_rounds; r++) { s.fri_vec_off.push_back(vec_words); vec_words += (big >> r) * 4; }
     for (uint32_t r = 0; r < s.n_rounds; r++) { s.fri_layer_off.push_back(layer_words); layer_words += mmcs_layer_words(big >> (r + 1)); }
@@ -434,21 +606,35 @@ int FibProver::init(uint32_t log_n, const FriParams& fp, hipStream_t stream, boo
     if ((rc = s.alloc(&s.fri_layers, layer_words + 8))) return rc;
     s.bary_blocks = (uint32_t)std::min<size_t>(1024, (n + BARY_BLOCK - 1) / BARY_BLOCK);
     if ((rc = s.alloc(&s.partials, (size_t)s.bary_blocks * 32))) return rc;
-    if ((rc = s.alloc(&s.small, 64))) return rc;
+    const size_t fpl = (size_t)1 << fp.log_final_poly_len;
+    if ((rc = s.alloc(&s.fp_ev, fpl * 4))) return rc;
+    {
+        uint32_t* p = nullptr;
+        if ((rc = s.alloc(&p, (sizeof(DevState) + 3) / 4))) return rc;
+        s.ds = reinterpret_cast<DevState*>(p);
+        P3_HIP(hipMemset(s.ds, 0, sizeof(DevState)));
+    }
     // query staging: per query one slot holding every tree's (row, path)
     size_t slot = (2 + s.log_big * 8) + (4 + s.log_big * 8);
     for (uint32_t r = 0; r < s.n_rounds; r++) slot += 8 + (size_t)(s.log_big - 1 - r) * 8;
     s.slot_words = slot;
-    if ((rc = s.alloc(&s.qstage, slot * std::max<uint32_t>(fp.num_queries, 1)))) return rc;
-    if ((rc = s.alloc(&s.qidx, std::max<uint32_t>(fp.num_queries, 1)))) return rc;
+    const uint32_t nq = fp.num_queries;
+    StageLayout& L = s.lay;
+    L.fpoly = L.froots + 8 * s.n_rounds;
+    L.witness = L.fpoly + 4 * (uint32_t)fpl;
+    L.status = L.witness + 1;
+    L.qidx = L.status + 1;
+    L.slots = (L.qidx + nq + 3u) & ~3u;
+    const size_t stage_words = (size_t)L.slots + slot * nq;
+    if (stage_words > 0xffffffffull) return fail(ERR_BAD_ARG, "fib prover: proof staging buffer too large");
+    L.words = (uint32_t)stage_words;
+    if ((rc = s.alloc(&s.pstage, stage_words))) return rc;
+    if ((rc = s.alloc(&s.qidx, std::max<uint32_t>(nq, 1)))) return rc;
     uint32_t* qt = nullptr;
     if ((rc = s.alloc(&qt, (sizeof(QTree) / 4) * (s.n_rounds + 2)))) return rc;
     s.qtrees = reinterpret_cast<QTree*>(qt);
-    s.host_pinned_words = std::max<size_t>(std::max<size_t>((size_t)s.bary_blocks * 32, slot * std::max<uint32_t>(fp.num_queries, 1)),
-                                           (size_t)4 << fp.log_final_poly_len) + 64;
-    P3_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.host_pinned), s.host_pinned_words * 4));
-    P3_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.host_roots), 64 * 32, hipHostMallocMapped));
-    P3_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&s.dev_roots), s.host_roots, 0));
+    P3_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.host_stage), stage_words * 4 + 64));
+    for (auto& e : s.ev) P3_HIP(hipEventCreate(&e));
     // device descriptors of the trees opened per query (fixed for the prover's lifetime)
     std::vector<QTree> qd;
     uint32_t off = 0;
@@ -489,11 +675,10 @@ static int get_selectors(Context& cx, hipStream_t stream, uint32_t log_n, const 
     return OK;
 }
 
-static double now_ms() {
-    using namespace std::chrono;
-    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
-}
-
+// Everything is ENQUEUED: the transcript runs on the device between the bulk kernels, so the host synchronises once
+// per proof, when the staging buffer (commitments, opened values, final polynomial, witness, query openings) has
+// landed in pinned memory.  The only other synchronisations are the rare continuation of a proof-of-work search whose
+// first range (16x the expected number of candidates) held no witness.
 int FibProver::prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof) {
     Impl& s = *im;
     Context* cxp;
@@ -507,31 +692,28 @@ int FibProver::prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof) {
     const uint32_t n = 1u << log_n, big = 1u << log_big;
     const uint32_t gen = bb::to_monty(bb::GEN);
     const uint32_t g_n = bb::two_adic_generator(log_n), g_n_inv = bb::inv(g_n);
-    double t0 = now_ms();
+    const StageLayout& L = s.lay;
+    const TsArgs ts{s.ds, s.pstage, s.hash, L};
+    auto commit = [&](const uint32_t* mat, size_t h, size_t w, uint32_t* layers, uint32_t root_slot) -> int {
+        const uint32_t* mp[1] = {mat};
+        size_t hh[1] = {h}, ww[1] = {w};
+        Tree* tp = nullptr;
+        int r = mmcs_commit(st, mp, hh, ww, 1, &tp, layers, s.pstage + root_slot, s.hash);
+        if (r) return r;
+        std::unique_ptr<Tree> t(tp);  // the layers live in the arena; the descriptor is not needed again
+        if (!t->root_copied)
+            P3_HIP(hipMemcpyAsync(s.pstage + root_slot, t->layers + t->layer_off.back(), 32, hipMemcpyDeviceToDevice, st));
+        return OK;
+    };
+    P3_HIP(hipEventRecord(s.ev[0], st));
 
     // ---- trace + commit (pcs.commit: bit-reversed coset LDE, shift GENERATOR) ----
     if ((rc = fib_trace(st, a, b, n, s.trace))) return rc;
     if ((rc = ntt_coset_lde(cx, st, s.trace, s.lde_t, n, 2, s.fp.log_blowup, gen, true))) return rc;
-    const uint32_t* mp[1] = {s.lde_t};
-    size_t hh[1] = {big}, ww[1] = {2};
-    Tree* tp = nullptr;
-    if ((rc = mmcs_commit(st, mp, hh, ww, 1, &tp, s.layers_t, s.dev_roots, s.hash))) return rc;
-    std::unique_ptr<Tree> tree_t(tp);
-    // public values: first row and last right value
-    uint32_t* hp = s.host_pinned;
-    if (!tree_t->root_copied) P3_HIP(hipMemcpyAsync(s.host_roots, tree_t->layers + tree_t->layer_off.back(), 32, hipMemcpyDeviceToHost, st));
-    P3_HIP(hipMemcpyAsync(hp + 8, s.trace, 8, hipMemcpyDeviceToHost, st));
-    P3_HIP(hipMemcpyAsync(hp + 10, s.trace + 2 * (size_t)(n - 1) + 1, 4, hipMemcpyDeviceToHost, st));
-    P3_HIP(hipStreamSynchronize(st));
-    uint32_t root_t[8], pis[3] = {hp[8], hp[9], hp[10]};
-    memcpy(root_t, s.host_roots, 32);
-    double t1 = now_ms();
-    Challenger ch(s.hash);
-    ch.observe(bb::to_monty(log_n));
-    ch.observe(bb::to_monty(log_n));
-    ch.observe_digest(root_t);
-    ch.observe_n(pis, 3);
-    Ext alpha = ch.sample_ext();
+    if ((rc = commit(s.lde_t, big, 2, s.layers_t, L.root_t))) return rc;
+    hipLaunchKernelGGL(ts_begin_kernel, dim3(1), dim3(64), 0, st, ts, s.trace, n, log_n);
+    P3_HIP(hipGetLastError());
+    P3_HIP(hipEventRecord(s.ev[1], st));
 
     // ---- quotient values + commit (shift GENERATOR/GENERATOR = 1) ----
     const uint2* sel = nullptr;
@@ -541,27 +723,18 @@ int FibProver::prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof) {
         qa.lde = reinterpret_cast<const uint2*>(s.lde_t);
         qa.sel = sel;
         qa.out = s.qflat;
+        qa.ds = s.ds;
         if ((rc = cx.get_root_table(st, log_n, false, &qa.roots))) return rc;
         qa.n = n; qa.log_n = log_n; qa.gen = gen; qa.ginv = g_n_inv;
         qa.zh_inv = bb::inv(bb::sub(bb::pow(gen, n), bb::ONE));
-        memcpy(qa.pis, pis, 12);
-        qa.apow[0] = bb::ext_one();
-        for (int k = 1; k < 5; k++) qa.apow[k] = bb::mul(qa.apow[k - 1], alpha);
         hipLaunchKernelGGL(fib_quotient_kernel, dim3((n + 255) / 256), dim3(256), 0, st, qa);
         P3_HIP(hipGetLastError());
     }
     if ((rc = ntt_coset_lde(cx, st, s.qflat, s.lde_q, n, 4, s.fp.log_blowup, bb::ONE, true))) return rc;
-    mp[0] = s.lde_q; ww[0] = 4;
-    if ((rc = mmcs_commit(st, mp, hh, ww, 1, &tp, s.layers_q, s.dev_roots + 8, s.hash))) return rc;
-    std::unique_ptr<Tree> tree_q(tp);
-    uint32_t root_q[8];
-    if (!tree_q->root_copied) P3_HIP(hipMemcpyAsync(s.host_roots + 8, tree_q->layers + tree_q->layer_off.back(), 32, hipMemcpyDeviceToHost, st));
-    P3_HIP(hipStreamSynchronize(st));
-    memcpy(root_q, s.host_roots + 8, 32);
-    double t2 = now_ms();
-    ch.observe_digest(root_q);
-    Ext zeta = ch.sample_ext();
-    Ext zeta_next = bb::scale(zeta, g_n);
+    if ((rc = commit(s.lde_q, big, 4, s.layers_q, L.root_q))) return rc;
+    hipLaunchKernelGGL(ts_zeta_kernel, dim3(1), dim3(64), 0, st, ts, g_n);
+    P3_HIP(hipGetLastError());
+    P3_HIP(hipEventRecord(s.ev[2], st));
 
     // ---- pcs.open: opened values ----
     TwoLevelTable roots_big;
@@ -569,30 +742,18 @@ int FibProver::prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof) {
     {
         uint32_t threads = (big + DEN_CHUNK - 1) / DEN_CHUNK;
         hipLaunchKernelGGL(inv_denoms_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, roots_big, big, log_big, gen,
-                           den_consts(zeta), den_consts(zeta_next), s.d0, s.d1);
+                           s.ds, s.d0, s.d1);
         P3_HIP(hipGetLastError());
         hipLaunchKernelGGL(barycentric_kernel, dim3(s.bary_blocks), dim3(BARY_BLOCK), 0, st, roots_big, n, log_big, gen,
                            reinterpret_cast<const uint2*>(s.lde_t), reinterpret_cast<const uint4*>(s.lde_q), s.d0, s.d1,
                            s.partials);
         P3_HIP(hipGetLastError());
+        const uint32_t sn = bb::pow(gen, n);
+        const uint32_t denom = bb::inv(bb::mul(bb::to_monty(n), sn));
+        hipLaunchKernelGGL(ts_open_kernel, dim3(1), dim3(TS_OPEN_THREADS), 0, st, ts, s.partials, s.bary_blocks, log_n, sn, denom);
+        P3_HIP(hipGetLastError());
     }
-    P3_HIP(hipMemcpyAsync(hp, s.partials, (size_t)s.bary_blocks * 128, hipMemcpyDeviceToHost, st));
-    P3_HIP(hipStreamSynchronize(st));
-    Ext opened[8];
-    for (int k = 0; k < 8; k++) opened[k] = bb::ext_zero();
-    for (uint32_t blk = 0; blk < s.bary_blocks; blk++)
-        for (int k = 0; k < 8; k++)
-            for (int c = 0; c < 4; c++) opened[k].c[c] = bb::add(opened[k].c[c], hp[blk * 32 + 4 * k + c]);
-    {
-        uint32_t sn = bb::pow(gen, n);
-        uint32_t denom = bb::inv(bb::mul(bb::to_monty(n), sn));
-        Ext f0 = bb::scale(bb::sub(bb::pow(zeta, n), bb::ext_from_base(sn)), denom);
-        Ext f1 = bb::scale(bb::sub(bb::pow(zeta_next, n), bb::ext_from_base(sn)), denom);
-        for (int k = 0; k < 8; k++) opened[k] = bb::mul(opened[k], (k == 2 || k == 3) ? f1 : f0);
-    }
-    for (int k = 0; k < 8; k++) ch.observe_ext(opened[k]);
-    Ext al = ch.sample_ext();
-    double t3 = now_ms();
+    P3_HIP(hipEventRecord(s.ev[3], st));
 
     // ---- reduced openings -> FRI input ----
     {
@@ -600,146 +761,108 @@ int FibProver::prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof) {
         ra.lde_t = reinterpret_cast<const uint2*>(s.lde_t);
         ra.lde_q = reinterpret_cast<const uint4*>(s.lde_q);
         ra.d0 = s.d0; ra.d1 = s.d1; ra.ro = s.fri_vec + s.fri_vec_off[0]; ra.big = big;
-        ra.alp[0] = bb::ext_one();
-        for (int k = 1; k < 8; k++) ra.alp[k] = bb::mul(ra.alp[k - 1], al);
-        const Ext ry0 = bb::add(opened[0], bb::mul(ra.alp[1], opened[1]));
-        const Ext ry1 = bb::add(opened[2], bb::mul(ra.alp[1], opened[3]));
-        const Ext ry2 = bb::add(bb::add(opened[4], bb::mul(ra.alp[1], opened[5])),
-                                bb::add(bb::mul(ra.alp[2], opened[6]), bb::mul(ra.alp[3], opened[7])));
-        ra.y02 = bb::add(ry0, bb::mul(ra.alp[4], ry2));
-        ra.y1 = bb::mul(ra.alp[2], ry1);
+        ra.ds = s.ds;
         hipLaunchKernelGGL(reduced_openings_kernel, dim3((big + 255) / 256), dim3(256), 0, st, ra);
         P3_HIP(hipGetLastError());
     }
 
     // ---- FRI commit phase ----
-    std::vector<std::unique_ptr<Tree>> ftrees;
-    std::vector<uint32_t> froots((size_t)s.n_rounds * 8);
     const uint32_t one_half = bb::inv(bb::to_monty(2));
     for (uint32_t r = 0; r < s.n_rounds; r++) {
         uint32_t len = big >> r, half = len >> 1;
-        mp[0] = s.fri_vec + s.fri_vec_off[r];
-        hh[0] = half; ww[0] = 8;  // ExtensionMmcs: rows of two ext elements, flattened
-        uint32_t slot = 16 + 8 * (r % 32);
-        if ((rc = mmcs_commit(st, mp, hh, ww, 1, &tp, s.fri_layers + s.fri_layer_off[r], s.dev_roots + slot, s.hash))) return rc;
-        ftrees.emplace_back(tp);
-        if (!tp->root_copied) P3_HIP(hipMemcpyAsync(s.host_roots + slot, tp->layers + tp->layer_off.back(), 32, hipMemcpyDeviceToHost, st));
-        P3_HIP(hipStreamSynchronize(st));
-        memcpy(&froots[(size_t)r * 8], s.host_roots + slot, 32);
-        ch.observe_digest(&froots[(size_t)r * 8]);
-        Ext beta = ch.sample_ext();
+        // ExtensionMmcs: rows of two ext elements, flattened
+        if ((rc = commit(s.fri_vec + s.fri_vec_off[r], half, 8, s.fri_layers + s.fri_layer_off[r], L.froots + 8 * r))) return rc;
+        hipLaunchKernelGGL(ts_fri_round_kernel, dim3(1), dim3(64), 0, st, ts, r, one_half);
+        P3_HIP(hipGetLastError());
         TwoLevelTable inv_roots;
         uint32_t log_half = log_big - 1 - r;
         if ((rc = cx.get_root_table(st, log_half + 1, true, &inv_roots))) return rc;
         hipLaunchKernelGGL(fri_fold_kernel, dim3((half + 255) / 256), dim3(256), 0, st, inv_roots,
-                           s.fri_vec + s.fri_vec_off[r], s.fri_vec + s.fri_vec_off[r + 1], half, log_half,
-                           bb::scale(beta, one_half), one_half);
+                           s.fri_vec + s.fri_vec_off[r], s.fri_vec + s.fri_vec_off[r + 1], half, log_half, s.ds, r, one_half);
         P3_HIP(hipGetLastError());
     }
-    // final polynomial: first 2^lfp entries (bit-reversed order) -> natural order -> inverse DFT on the host
+    // final polynomial: first 2^lfp entries (bit-reversed order) -> natural order -> inverse DFT (of the four base
+    // coordinates: the transform is linear over the base field) straight into the staging buffer
     const uint32_t fpl = 1u << s.fp.log_final_poly_len;
-    std::vector<Ext> fpoly(fpl);
-    {
-        P3_HIP(hipMemcpyAsync(hp, s.fri_vec + s.fri_vec_off[s.n_rounds], (size_t)fpl * 16, hipMemcpyDeviceToHost, st));
-        P3_HIP(hipStreamSynchronize(st));
-        std::vector<Ext> ev(fpl);
-        for (uint32_t i = 0; i < fpl; i++) {
-            uint32_t j = 0;
-            for (uint32_t k = 0; k < s.fp.log_final_poly_len; k++) j |= ((i >> k) & 1u) << (s.fp.log_final_poly_len - 1 - k);
-            memcpy(ev[i].c, hp + 4 * (size_t)j, 16);
-        }
-        // naive inverse DFT (fpl is tiny): c_k = 1/fpl * sum_i ev_i w^-(ik)
-        uint32_t winv = bb::inv(bb::two_adic_generator(s.fp.log_final_poly_len));
-        uint32_t ninv = bb::inv(bb::to_monty(fpl));
-        for (uint32_t k = 0; k < fpl; k++) {
-            Ext acc = bb::ext_zero();
-            for (uint32_t i = 0; i < fpl; i++) acc = bb::add(acc, bb::scale(ev[i], bb::pow(winv, (uint64_t)i * k)));
-            fpoly[k] = bb::scale(acc, ninv);
-            ch.observe_ext(fpoly[k]);
-        }
-    }
-    double t4 = now_ms();
+    if ((rc = bit_reverse_rows(st, s.fri_vec + s.fri_vec_off[s.n_rounds], s.fp_ev, fpl, 4))) return rc;
+    if ((rc = ntt_dft(cx, st, s.fp_ev, s.pstage + L.fpoly, fpl, 4, true))) return rc;
+    const uint32_t pow_mask = (1u << s.fp.proof_of_work_bits) - 1u;
+    hipLaunchKernelGGL(ts_final_kernel, dim3(1), dim3(64), 0, st, ts, fpl, pow_mask);
+    P3_HIP(hipGetLastError());
+    P3_HIP(hipEventRecord(s.ev[4], st));
 
-    // ---- proof of work ----
-    uint32_t witness = 0;
+    // ---- proof of work: two launches, no synchronisation.  The first covers 2x the expected number of candidates
+    // (every block of a launch is resident before the first one finishes, so a wider first launch would simply do
+    // all of its work); the second covers up to 16x and its blocks return at once when the first found a witness
+    // (P[first misses] = e^-2, P[both miss] = e^-16: then the host continues the search after the proof's sync).
+    auto grind = [&](uint64_t base, uint32_t count) -> int {
+        if (s.hash == HASH_KECCAK) hipLaunchKernelGGL(grind_keccak_kernel, dim3(count / 256), dim3(256), 0, st, s.ds, pow_mask, (uint32_t)base);
+        else hipLaunchKernelGGL(grind_kernel, dim3(count / 256), dim3(256), 0, st, s.ds, pow_mask, (uint32_t)base);
+        P3_HIP(hipGetLastError());
+        return OK;
+    };
+    // P3HIP_GRIND_FIRST_LOG (tests): log2 of the whole first search range, to exercise the continuation path
+    const uint32_t first_log = [] { const char* e = getenv("P3HIP_GRIND_FIRST_LOG"); return e ? (uint32_t)atoi(e) : 0u; }();
+    uint32_t batch = 1u << std::min<uint32_t>(std::max<uint32_t>(first_log ? first_log : s.fp.proof_of_work_bits + 4, 8), 24);
     {
-        uint32_t mask = (1u << s.fp.proof_of_work_bits) - 1u;
-        KeccakGrindArgs ka{};
-        uint32_t pos = 0;
-        if (s.hash == HASH_KECCAK) {
-            // pending input = chaining digest + the bytes observed since; complete blocks are absorbed here
-            size_t done = keccak256_absorb_full(ka.state, ch.ibuf.data(), ch.ibuf.size());
-            size_t tail = ch.ibuf.size() - done;
-            uint8_t tmpl[272] = {0};
-            memcpy(tmpl, ch.ibuf.data() + done, tail);
-            size_t end = tail + 4;                       // message end within the template
-            ka.n_blocks = end < 136 ? 1 : 2;
-            tmpl[end] ^= 0x01;
-            tmpl[(size_t)ka.n_blocks * 136 - 1] ^= 0x80;
-            memcpy(ka.block, tmpl, 272);
-            ka.wpos = (uint32_t)tail;
-            ka.mask = mask;
-            hp[16] = 0xffffffffu;
-            P3_HIP(hipMemcpyAsync(s.small + 16, hp + 16, 4, hipMemcpyHostToDevice, st));
-        } else {
-            Challenger c2 = ch;  // state with the pending inputs applied, witness slot = n_in
-            uint32_t pre[16];
-            memcpy(pre, c2.state, 64);
-            for (int i = 0; i < c2.n_in; i++) pre[i] = c2.in[i];
-            pos = (uint32_t)c2.n_in;
-            memcpy(hp, pre, 64);
-            hp[16] = 0xffffffffu;
-            P3_HIP(hipMemcpyAsync(s.small, hp, 68, hipMemcpyHostToDevice, st));
-        }
-        // expected 2^bits candidates: first launch covers 2x that (P[miss] = e^-2), each later one 4x the previous
-        uint32_t batch = 1u << std::min<uint32_t>(std::max<uint32_t>(s.fp.proof_of_work_bits + 1, 10), 24);
-        uint32_t found = 0xffffffffu;
-        for (uint64_t base = 0; base < bb::P && found == 0xffffffffu; base += batch, batch = std::min<uint32_t>(batch * 4, 1u << 24)) {
-            if (s.hash == HASH_KECCAK) {
-                ka.base = (uint32_t)base;
-                hipLaunchKernelGGL(grind_keccak_kernel, dim3(batch / 256), dim3(256), 0, st, ka, s.small + 16);
-            } else {
-                hipLaunchKernelGGL(grind_kernel, dim3(batch / 256), dim3(256), 0, st, s.small, pos, mask, (uint32_t)base, s.small + 16);
-            }
-            P3_HIP(hipGetLastError());
-            P3_HIP(hipMemcpyAsync(hp + 32, s.small + 16, 4, hipMemcpyDeviceToHost, st));
-            P3_HIP(hipStreamSynchronize(st));
-            found = hp[32];
-        }
-        if (found == 0xffffffffu) return fail(ERR_INTERNAL, "grind: no proof-of-work witness found");
-        witness = bb::to_monty(found);
-        if (!ch.check_witness(s.fp.proof_of_work_bits, witness)) return fail(ERR_INTERNAL, "grind: witness rejected by the host challenger");
+        const uint32_t head = first_log ? batch : std::min<uint32_t>(batch, 1u << std::max<uint32_t>(s.fp.proof_of_work_bits + 1, 8));
+        if ((rc = grind(0, head))) return rc;
+        if (batch > head && (rc = grind(head, batch - head))) return rc;
     }
-    double t5 = now_ms();
+    P3_HIP(hipEventRecord(s.ev[5], st));
 
     // ---- query phase ----
     const uint32_t nq = s.fp.num_queries;
-    std::vector<uint32_t> qidx(nq);
-    for (uint32_t q = 0; q < nq; q++) qidx[q] = (uint32_t)ch.sample_bits(log_big);
-    if (nq) {
-        memcpy(hp, qidx.data(), (size_t)nq * 4);
-        P3_HIP(hipMemcpyAsync(s.qidx, hp, (size_t)nq * 4, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(query_gather_kernel, dim3(nq, s.n_rounds + 2), dim3(64), 0, st, s.qtrees, s.n_rounds + 2, s.qidx,
-                           (uint32_t)s.slot_words, s.qstage);
+    auto queries = [&]() -> int {
+        hipLaunchKernelGGL(ts_queries_kernel, dim3(1), dim3(64), 0, st, ts, nq, log_big, s.fp.proof_of_work_bits, s.qidx);
         P3_HIP(hipGetLastError());
-        P3_HIP(hipMemcpyAsync(hp, s.qstage, (size_t)nq * s.slot_words * 4, hipMemcpyDeviceToHost, st));
+        if (nq) {
+            hipLaunchKernelGGL(query_gather_kernel, dim3(nq, s.n_rounds + 2), dim3(64), 0, st, s.qtrees, s.n_rounds + 2, s.qidx,
+                               (uint32_t)s.slot_words, s.pstage + L.slots);
+            P3_HIP(hipGetLastError());
+        }
+        P3_HIP(hipMemcpyAsync(s.host_stage, s.pstage, (size_t)L.words * 4, hipMemcpyDeviceToHost, st));
+        return OK;
+    };
+    if ((rc = queries())) return rc;
+    P3_HIP(hipEventRecord(s.ev[6], st));
+    P3_HIP(hipStreamSynchronize(st));  // the one synchronisation of a proof
+    const uint32_t* hp = s.host_stage;
+    static const bool trace = getenv("P3HIP_TRACE") != nullptr;
+#define TR(...) do { if (trace) { fprintf(stderr, __VA_ARGS__); fflush(stderr); } } while (0)
+    TR("prove: synced, status %u\n", hp[L.status]);
+    if (hp[L.status] == ST_GRIND_MISS) {
+        // continue the search range by range (each 4x the previous one), then redo the query phase
+        uint32_t found = 0xffffffffu;
+        for (uint64_t base = batch; base < bb::P && found == 0xffffffffu; base += batch) {
+            batch = std::min<uint32_t>(batch * 4, 1u << 24);
+            TR("prove: continue search base %llu batch %u\n", (unsigned long long)base, batch);
+            if ((rc = grind(base, batch))) return rc;
+            P3_HIP(hipMemcpyAsync(&found, &s.ds->grind_result, 4, hipMemcpyDeviceToHost, st));
+            P3_HIP(hipStreamSynchronize(st));
+            TR("prove: found %u\n", found);
+        }
+        if (found == 0xffffffffu) return fail(ERR_INTERNAL, "grind: no proof-of-work witness found");
+        if ((rc = queries())) return rc;
         P3_HIP(hipStreamSynchronize(st));
+        TR("prove: queries redone, status %u\n", hp[L.status]);
     }
+    if (hp[L.status] != 0) return fail(ERR_INTERNAL, "grind: witness rejected by the device transcript");
 
     // ---- serialise (same layout as the test oracle's restatement) ----
     std::vector<uint8_t>& pf = *proof;
     pf.clear();
     pf.reserve(64 + (size_t)nq * s.slot_words * 4 + 4096);
     put_u32(pf, 0x42463350u); put_u32(pf, 1); put_u32(pf, log_n);
-    put_words(pf, root_t, 8); put_words(pf, root_q, 8);
-    put_u32(pf, 2); put_words(pf, opened[0].c, 4); put_words(pf, opened[1].c, 4);
-    put_u32(pf, 2); put_words(pf, opened[2].c, 4); put_words(pf, opened[3].c, 4);
-    put_u32(pf, 1); put_u32(pf, 4);
-    for (int k = 4; k < 8; k++) put_words(pf, opened[k].c, 4);
-    put_u32(pf, s.n_rounds); put_words(pf, froots.data(), froots.size());
+    put_words(pf, hp + L.root_t, 8); put_words(pf, hp + L.root_q, 8);
+    const uint32_t* op = hp + L.opened;
+    put_u32(pf, 2); put_words(pf, op, 8);
+    put_u32(pf, 2); put_words(pf, op + 8, 8);
+    put_u32(pf, 1); put_u32(pf, 4); put_words(pf, op + 16, 16);
+    put_u32(pf, s.n_rounds); put_words(pf, hp + L.froots, (size_t)s.n_rounds * 8);
     put_u32(pf, nq);
     for (uint32_t q = 0; q < nq; q++) {
-        const uint32_t* slot = hp + (size_t)q * s.slot_words;
+        const uint32_t* slot = hp + L.slots + (size_t)q * s.slot_words;
         put_u32(pf, 2);
         put_u32(pf, 1); put_u32(pf, 2); put_words(pf, slot, 2); put_u32(pf, log_big); put_words(pf, slot + 2, (size_t)log_big * 8);
         slot += 2 + log_big * 8;
@@ -748,18 +871,21 @@ int FibProver::prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof) {
         put_u32(pf, s.n_rounds);
         for (uint32_t r = 0; r < s.n_rounds; r++) {
             uint32_t lh = log_big - 1 - r;
-            uint32_t idx = qidx[q] >> r;
+            uint32_t idx = hp[L.qidx + q] >> r;
             put_words(pf, slot + 4 * ((idx ^ 1) & 1), 4);  // sibling_value
             put_u32(pf, lh); put_words(pf, slot + 8, (size_t)lh * 8);
             slot += 8 + lh * 8;
         }
     }
     put_u32(pf, fpl);
-    for (uint32_t k = 0; k < fpl; k++) put_words(pf, fpoly[k].c, 4);
-    put_u32(pf, witness);
-    double t6 = now_ms();
-    s.times.trace_commit_ms += t1 - t0; s.times.quotient_commit_ms += t2 - t1; s.times.open_ms += t3 - t2;
-    s.times.fri_commit_ms += t4 - t3; s.times.grind_ms += t5 - t4; s.times.query_ms += t6 - t5; s.times.proofs += 1;
+    put_words(pf, hp + L.fpoly, (size_t)fpl * 4);
+    put_u32(pf, hp[L.witness]);
+    TR("prove: serialised %zu bytes\n", pf.size());
+    // stage times on the device timeline (events between the stages of the stream)
+    float ms[N_STAGE_EVENTS - 1] = {0};
+    for (int k = 0; k + 1 < N_STAGE_EVENTS; k++) (void)hipEventElapsedTime(&ms[k], s.ev[k], s.ev[k + 1]);
+    s.times.trace_commit_ms += ms[0]; s.times.quotient_commit_ms += ms[1]; s.times.open_ms += ms[2];
+    s.times.fri_commit_ms += ms[3]; s.times.grind_ms += ms[4]; s.times.query_ms += ms[5]; s.times.proofs += 1;
     return OK;
 }
 

@@ -1,0 +1,205 @@
+// Device-resident Fiat-Shamir transcript of the fib_air prover: the challengers of challenger.h restated for ONE
+// WAVEFRONT, so that observe-root -> sample-challenge -> next kernel needs no host round trip.
+//   HASH_POSEIDON2  DuplexChallenger<BabyBear, Poseidon2-16, 16, 8>: the sponge state is spread over the 16 lanes of a
+//                   DPP row (poseidon2_coop.cuh: ~1.1k wave-instructions of latency per permutation instead of ~7k for a
+//                   single lane); every row of the wave carries the same state, so every lane sees the same results.
+//   HASH_KECCAK     SerializingChallenger32<BabyBear, HashChallenger<u8, Keccak256Hash, 32>> (native/src/fib_air.rs:53):
+//                   kept as a STREAMING sponge — the chaining digest and the observed bytes are absorbed as they arrive,
+//                   so at any time the state is "full blocks absorbed + a partial block", which is also exactly what
+//                   the proof-of-work search needs.  Lane 0 runs it; results are broadcast.
+// Same conventions as the host classes (p3-challenger 0.4.2 is absent: [UPSTREAM-RECALL], see challenger.h); the proofs
+// these produce are compared byte for byte with the host transcript of the CPU restatement in tests/.
+#pragma once
+#include "bb31.cuh"
+#include "keccak.cuh"
+#include "mmcs.h"
+#include "poseidon2_coop.cuh"
+
+namespace p3 {
+
+// 1/(z - x) through the quadratic tower needs these constants of the point z (prover.hip inv_denoms_kernel)
+struct DenConsts {
+    uint32_t z0, z1, z2, z3, k0, k1, c1, z2w, z3w;
+};
+BB_HD DenConsts den_consts(const bb::Ext& z) {
+    DenConsts k{};
+    k.z0 = z.c[0]; k.z1 = z.c[1]; k.z2 = z.c[2]; k.z3 = z.c[3];
+    const uint32_t W = bb::W_MONTY;
+    // B^2 = (z1^2 + W z3^2) + 2 z1 z3 Y;  Y B^2 = W * 2 z1 z3 + (z1^2 + W z3^2) Y = c0 + c1 Y
+    uint32_t b0 = bb::add(bb::sqr(z.c[1]), bb::mul(W, bb::sqr(z.c[3]))), b1 = bb::dbl(bb::mul(z.c[1], z.c[3]));
+    uint32_t c0 = bb::mul(W, b1);
+    k.c1 = b0;
+    k.k0 = bb::sub(bb::mul(W, bb::sqr(z.c[2])), c0);  // A^2 = (a0^2 + W z2^2) + 2 a0 z2 Y
+    k.k1 = bb::dbl(z.c[2]);
+    k.z2w = bb::mul(W, z.c[2]);
+    k.z3w = bb::mul(W, z.c[3]);
+    return k;
+}
+
+// The Keccak-256 proof-of-work search starts from the sponge state after the complete blocks plus up to two
+// template blocks (pending tail bytes, zeroed witness bytes, 0x01 / 0x80 padding).
+struct KeccakGrindArgs {
+    uint64_t state[25];
+    uint64_t block[2][17];
+    uint32_t n_blocks, wpos;  // witness byte offset within the template (may straddle lanes and blocks)
+    uint32_t mask, base;
+};
+
+constexpr uint32_t MAX_FRI_ROUNDS = 32;
+constexpr uint32_t ST_GRIND_MISS = 1u;  // the first search range held no witness: the host continues the search
+
+// HashChallenger<u8, Keccak256, 32> as a streaming sponge.  Lives in HBM between kernels (DevState::kc) and in LDS
+// while a transcript kernel runs (byte-wise updates of HBM would cost a memory round trip each).
+struct KState {
+    uint64_t st[25];
+    uint32_t blen, n_obuf;
+    uint8_t blk[136];
+    uint8_t obuf[32];
+};
+static_assert(sizeof(KState) % 8 == 0, "KState is copied as 64-bit words");
+
+// Everything the transcript produces and the later kernels consume; one per prover, in HBM.
+struct DevState {
+    // DuplexChallenger
+    uint32_t st[16], inb[8], outb[8], n_in, n_out;
+    KState kc;
+    // challenges and what is derived from them
+    uint32_t pis[4];
+    bb::Ext apow[5];                  // alpha^0..4
+    bb::Ext zeta, zeta_next;
+    DenConsts k0, k1;
+    bb::Ext alp[8], y02, y1;          // batching challenge powers, ry0 + alpha^4 ry2, alpha^2 ry1
+    bb::Ext half_beta[MAX_FRI_ROUNDS];
+    uint32_t grind_result;            // atomicMin target: smallest canonical witness found so far
+    uint32_t status;
+    KeccakGrindArgs kgrind;
+};
+
+// ---- Keccak streaming sponge on the LDS copy; called by lane 0 only.  Not inlined: one copy of the permutation per
+// kernel, and the challenger object itself stays in registers.
+__device__ __noinline__ void k_absorb_block(KState* k) {
+    uint64_t a[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) a[i] = k->st[i];
+#pragma unroll
+    for (int i = 0; i < 17; i++) {
+        uint64_t w = 0;
+        for (int b = 0; b < 8; b++) w |= (uint64_t)k->blk[8 * i + b] << (8 * b);
+        a[i] ^= w;
+    }
+    kk::permute(a);
+#pragma unroll
+    for (int i = 0; i < 25; i++) k->st[i] = a[i];
+    k->blen = 0;
+}
+__device__ __forceinline__ void k_observe_byte(KState* k, uint8_t b) {
+    k->n_obuf = 0;
+    k->blk[k->blen++] = b;
+    if (k->blen == 136) k_absorb_block(k);
+}
+__device__ __noinline__ void k_flush(KState* k) {  // output = Keccak256(input); the digest also starts the next input
+    uint32_t n = k->blen;
+    for (uint32_t i = n; i < 136; i++) k->blk[i] = 0;
+    k->blk[n] ^= 0x01;
+    k->blk[135] ^= 0x80;
+    k_absorb_block(k);
+    for (int i = 0; i < 32; i++) k->obuf[i] = (uint8_t)(k->st[i >> 3] >> (8 * (i & 7)));
+    for (int i = 0; i < 25; i++) k->st[i] = 0;
+    for (int i = 0; i < 32; i++) k->blk[i] = k->obuf[i];
+    k->blen = 32;
+    k->n_obuf = 32;
+}
+__device__ __noinline__ uint32_t k_sample(KState* k) {
+    for (;;) {  // rejection sampling of a 31-bit value below P
+        uint32_t v = 0;
+        for (int i = 0; i < 4; i++) {
+            if (!k->n_obuf) k_flush(k);
+            v |= (uint32_t)k->obuf[--k->n_obuf] << (8 * i);
+        }
+        v &= 0x7fffffffu;
+        if (v < bb::P) return bb::to_monty(v);
+    }
+}
+
+// One copy of the lane-cooperative permutation per kernel: every observe / sample site would otherwise inline it.
+__device__ __noinline__ uint32_t coop_permute_call(uint32_t v) {
+    const p2c::LaneConst lc = p2c::lane_constants(threadIdx.x & 15u);
+    return p2c::permute(v, lc);
+}
+
+// ---- the wave-wide challenger ---------------------------------------------------------------------------------
+struct DevChal {
+    int kind;
+    DevState* ds;
+    KState* k;  // Keccak configuration: the sponge, in LDS (one KState of __shared__ memory per transcript kernel)
+    uint32_t lane16;
+    uint32_t st, inb, outb, n_in, n_out;  // lane i of each row holds state[i], in[i], out[i]
+
+    // called by the first wave of the workgroup (threadIdx.x < 64); lds: one KState of shared memory
+    __device__ __forceinline__ void begin(int kind_, DevState* ds_, KState* lds, bool fresh) {
+        kind = kind_; ds = ds_; k = lds;
+        lane16 = threadIdx.x & 15u;
+        if (kind == HASH_KECCAK) {
+            uint64_t* d = reinterpret_cast<uint64_t*>(lds);
+            const uint64_t* s = reinterpret_cast<const uint64_t*>(&ds->kc);
+            for (uint32_t i = threadIdx.x; i < sizeof(KState) / 8; i += 64) d[i] = fresh ? 0ull : s[i];
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+            st = inb = outb = n_in = n_out = 0;
+            return;
+        }
+        if (fresh) { st = 0; inb = 0; outb = 0; n_in = 0; n_out = 0; return; }
+        st = ds->st[lane16];
+        inb = ds->inb[lane16 & 7u];
+        outb = ds->outb[lane16 & 7u];
+        n_in = ds->n_in; n_out = ds->n_out;
+    }
+    __device__ __forceinline__ void end() {
+        if (kind == HASH_KECCAK) {
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+            const uint64_t* s = reinterpret_cast<const uint64_t*>(k);
+            uint64_t* d = reinterpret_cast<uint64_t*>(&ds->kc);
+            for (uint32_t i = threadIdx.x; i < sizeof(KState) / 8; i += 64) d[i] = s[i];
+            return;
+        }
+        if (threadIdx.x < 16) ds->st[lane16] = st;
+        if (threadIdx.x < 8) { ds->inb[lane16] = inb; ds->outb[lane16] = outb; }
+        if (threadIdx.x == 0) { ds->n_in = n_in; ds->n_out = n_out; }
+    }
+    __device__ __forceinline__ void duplex() {
+        const uint32_t v = lane16 < n_in ? inb : st;
+        st = coop_permute_call(v);
+        outb = st;
+        n_in = 0; n_out = 8;
+    }
+    // ---- Keccak streaming sponge, lane 0 only (free functions on the LDS copy: see below the struct) ----
+    // ---- the challenger interface: every lane of the wave calls these with the same arguments ----
+    __device__ __forceinline__ void observe(uint32_t v) {  // a field element (Montgomery word)
+        if (kind == HASH_KECCAK) {
+            if ((threadIdx.x & 63u) == 0)
+                for (int i = 0; i < 4; i++) k_observe_byte(k, (uint8_t)(v >> (8 * i)));
+            return;
+        }
+        n_out = 0;
+        if (lane16 == n_in) inb = v;
+        n_in++;
+        if (n_in == 8) duplex();
+    }
+    __device__ __forceinline__ void observe_n(const uint32_t* v, uint32_t n) { for (uint32_t i = 0; i < n; i++) observe(v[i]); }
+    __device__ __forceinline__ void observe_ext(const bb::Ext& e) { observe_n(e.c, 4); }
+    __device__ __forceinline__ uint32_t sample() {
+        if (kind == HASH_KECCAK) {
+            uint32_t v = 0;
+            if ((threadIdx.x & 63u) == 0) v = k_sample(k);
+            return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+        }
+        if (n_in || !n_out) duplex();
+        n_out--;
+        return (uint32_t)__shfl((int)outb, (int)n_out, 16);
+    }
+    __device__ __forceinline__ bb::Ext sample_ext() { bb::Ext r; for (int i = 0; i < 4; i++) r.c[i] = sample(); return r; }
+    __device__ __forceinline__ uint32_t sample_bits(uint32_t bits) { return bb::from_monty(sample()) & ((1u << bits) - 1u); }
+};
+
+}  // namespace p3

@@ -50,6 +50,57 @@ def test_scatter_prove_gather_world2():
     assert allp == [_fake_proof(i, i, i + 1) for i in range(7)]
 
 
+def _fake_proof_step(step, i, a, b):
+    # ragged, and the LONGEST proof changes rank and length from step to step (the staging width follows it)
+    return (b"s%d-proof-%d-%d-%d|" % (step, i, a, b)) * (2 + (i * 7 + step * 5) % 9)
+
+
+def _worker_async(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_package
+    load_package()
+    from plonky3_mobile_amd import batch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # bench.py's loop: the gather of step k is still in flight while step k+1 fills the OTHER staging pair and
+    # starts its own gather; step k is collected only then.  Five steps reuse each of the two pairs at least twice.
+    n_total, results, pending = 7, [], None
+    for step in range(5):
+        inst = [(10 * step + i, 10 * step + i + 1) for i in range(n_total)] if rank == 0 else []
+        mine = batch.scatter_descriptors(inst)
+        local = [(i, _fake_proof_step(step, i, a, b)) for i, a, b in mine]
+        prev, pending = pending, batch.gather_proofs_async(local, n_total)
+        if prev is not None:
+            results.append(prev.wait())
+    results.append(pending.wait())
+    if rank == 0:
+        q.put(results)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_async_gather_double_buffer_reuse_world2():
+    """gather_proofs_async across five consecutive steps with ragged, step-dependent proof lengths: each step's
+    proofs come back complete and in instance order although the next step's staging was filled meanwhile."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_async, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    results = q.get(timeout=120)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert len(results) == 5
+    for step, allp in enumerate(results):
+        assert allp == [_fake_proof_step(step, i, 10 * step + i, 10 * step + i + 1) for i in range(7)], step
+
+
 def test_shard_instances_partition():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import load_package

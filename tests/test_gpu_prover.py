@@ -145,3 +145,22 @@ def test_reference_fri_parameters_n8(p3, oracle):
     proof = p3.FibAirProver(3, params=gfp).prove(0, 1)
     assert proof == oracle.prove_fib_air(0, 1, 3, ofp)
     assert oracle.verify_fib_air(proof, 0, 1, 21, 3, ofp) == 0
+
+
+@pytest.mark.parametrize("hash", ["poseidon2", "keccak"])
+def test_grind_search_continues_after_an_empty_first_range(p3, oracle, hash, monkeypatch):
+    """The device transcript covers 16x the expected number of proof-of-work candidates in its first launch; when that
+    range holds no witness the host continues the search range by range and redoes the query phase.  Forced here by a
+    first range of 256 candidates against 12 proof-of-work bits: the proof must still equal the oracle's."""
+    monkeypatch.setenv("P3HIP_GRIND_FIRST_LOG", "8")
+    gfp, ofp = _fp(p3, oracle, 1, 0, 12, 12)
+    kind = oracle.HASH_KECCAK if hash == "keccak" else oracle.HASH_POSEIDON2
+    pr = p3.FibAirProver(9, params=gfp, hash=hash)
+    hit_continuation = False
+    for a in range(4):
+        proof = pr.prove(a, a + 1)
+        assert proof == oracle.prove_fib_air(a, a + 1, 9, ofp, hash=kind)
+        witness = int(np.frombuffer(proof[-4:], np.uint32)[0])
+        hit_continuation |= int(oracle.from_monty(np.array([witness]))[0]) >= 256
+    assert hit_continuation, "no instance needed the continuation path: pick other instances"
+    pr.close()

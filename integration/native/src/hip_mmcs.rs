@@ -1,0 +1,193 @@
+// NEVER COMPILED HERE (no Rust toolchain in the build image; p3-* 0.4.2 path dependencies absent).
+//
+// native/src/hip_mmcs.rs — `HipMmcs`: `Mmcs<BabyBear>` whose Merkle trees are built and kept in HBM by libp3hip.
+// The reference hands Plonky3's own MMCS to the PCS (native/src/fib_air.rs:40-51); this type takes its place:
+//
+//     let val_mmcs = HipMmcs::keccak(field_hash, compress);          // the reference's hashes (fib_air.rs:28-38)
+//     let val_mmcs = HipMmcs::poseidon2(sponge, truncated_perm);     // north_star's configuration
+//
+// `commit` / `open_batch` run on the device (p3hip_mmcs_commit_hash / p3hip_mmcs_open_batch); `verify_batch` is the
+// verifier's job and stays Plonky3's own CPU code (the wrapped `MerkleTreeMmcs`), exactly as in the reference.
+// Trait shapes are those of p3-commit 0.4.2 as recalled (the crate is not in this container) — [UPSTREAM-RECALL].
+use core::ffi::c_void;
+use core::marker::PhantomData;
+
+use p3_baby_bear::BabyBear;
+use p3_commit::{BatchOpening, BatchOpeningRef, Mmcs};
+use p3_field::PackedValue;
+use p3_matrix::dense::RowMajorMatrix;
+use p3_matrix::{Dimensions, Matrix};
+use p3_merkle_tree::{MerkleTreeError, MerkleTreeMmcs};
+use p3_symmetric::{CryptographicHasher, Hash, PseudoCompressionFunction};
+use serde::{Deserialize, Serialize};
+
+pub const P3HIP_HASH_POSEIDON2: i32 = 0;
+pub const P3HIP_HASH_KECCAK: i32 = 1;
+
+#[repr(C)]
+pub struct p3hip_tree_t {
+    _private: [u8; 0],
+}
+
+// include/p3hip.h
+extern "C" {
+    fn p3hip_take_last_error() -> *const core::ffi::c_char;
+    fn p3hip_mmcs_commit_hash(
+        hash: i32,
+        mats: *const *const u32,
+        heights: *const usize,
+        widths: *const usize,
+        n_mats: usize,
+        root_out: *mut u32,
+        tree_out: *mut *mut p3hip_tree_t,
+    ) -> i32;
+    fn p3hip_mmcs_open_batch(tree: *const p3hip_tree_t, index: usize, rows_out: *mut u32, path_out: *mut u32, stream: *mut c_void) -> i32;
+    fn p3hip_mmcs_log_max_height(tree: *const p3hip_tree_t) -> usize;
+    fn p3hip_mmcs_free(tree: *mut p3hip_tree_t);
+}
+
+fn last_error() -> String {
+    unsafe {
+        let p = p3hip_take_last_error();
+        if p.is_null() {
+            "hip backend error".to_string()
+        } else {
+            std::ffi::CStr::from_ptr(p).to_string_lossy().into_owned()
+        }
+    }
+}
+
+/// Prover data: the committed matrices (host copies, for `get_matrices`) and the device tree (digest layers + device
+/// copies of the matrices, owned by libp3hip).  Freed with the handle.
+pub struct HipTree<M> {
+    handle: *mut p3hip_tree_t,
+    mats: Vec<M>,
+    widths: Vec<usize>,
+}
+unsafe impl<M: Send> Send for HipTree<M> {}
+unsafe impl<M: Sync> Sync for HipTree<M> {}
+impl<M> Drop for HipTree<M> {
+    fn drop(&mut self) {
+        unsafe { p3hip_mmcs_free(self.handle) }
+    }
+}
+
+/// A digest word: `BabyBear` (Poseidon2: 8 field elements) or `u64` (Keccak: `[u64; 4]`).  On the C side every digest
+/// is 8 little-endian `u32` words; for the Keccak configuration two of them make one `u64`, low half first.
+pub trait DigestWord: Copy + Default + Send + Sync + Serialize + for<'de> Deserialize<'de> + 'static {
+    const HASH_KIND: i32;
+    const DIGEST_ELEMS: usize;
+    fn from_words(words: &[u32; 8]) -> Vec<Self>;
+}
+impl DigestWord for BabyBear {
+    const HASH_KIND: i32 = P3HIP_HASH_POSEIDON2;
+    const DIGEST_ELEMS: usize = 8;
+    fn from_words(words: &[u32; 8]) -> Vec<Self> {
+        // Montgomery words, the representation BabyBear is repr(transparent) over (backend_vulkan.rs:2002-2005)
+        words.iter().map(|w| unsafe { core::mem::transmute::<u32, BabyBear>(*w) }).collect()
+    }
+}
+impl DigestWord for u64 {
+    const HASH_KIND: i32 = P3HIP_HASH_KECCAK;
+    const DIGEST_ELEMS: usize = 4;
+    fn from_words(words: &[u32; 8]) -> Vec<Self> {
+        (0..4).map(|i| words[2 * i] as u64 | ((words[2 * i + 1] as u64) << 32)).collect()
+    }
+}
+
+/// `Mmcs<BabyBear>` on the hip backend.  `W` is the digest word, `N` the digest length: `HipMmcs<.., BabyBear, 8>` for
+/// Poseidon2 (PaddingFreeSponge<Perm, 16, 8, 8> + TruncatedPermutation<Perm, 2, 8, 16>), `HipMmcs<.., u64, 4>` for the
+/// reference's Keccak configuration (SerializingHasher<PaddingFreeSponge<KeccakF, 25, 17, 4>> +
+/// CompressionFunctionFromHasher<_, 2, 4>).  `inner` is Plonky3's own tree over the SAME hasher and compressor: it
+/// verifies openings (CPU, verifier side) and pins the hash configuration the device tree must reproduce.
+#[derive(Clone, Debug)]
+pub struct HipMmcs<P, PW, H, C, W, const N: usize> {
+    inner: MerkleTreeMmcs<P, PW, H, C, N>,
+    _w: PhantomData<W>,
+}
+
+impl<P, PW, H, C, W, const N: usize> HipMmcs<P, PW, H, C, W, N> {
+    pub fn new(hash: H, compress: C) -> Self {
+        Self { inner: MerkleTreeMmcs::new(hash, compress), _w: PhantomData }
+    }
+}
+
+impl<P, PW, H, C, W, const N: usize> Mmcs<BabyBear> for HipMmcs<P, PW, H, C, W, N>
+where
+    P: PackedValue<Value = BabyBear>,
+    PW: PackedValue<Value = W>,
+    W: DigestWord + Eq,
+    H: CryptographicHasher<BabyBear, [W; N]> + CryptographicHasher<P, [PW; N]> + Sync + Clone,
+    C: PseudoCompressionFunction<[W; N], 2> + PseudoCompressionFunction<[PW; N], 2> + Sync + Clone,
+    [W; N]: Serialize + for<'de> Deserialize<'de>,
+{
+    type ProverData<M> = HipTree<M>;
+    type Commitment = Hash<BabyBear, W, N>;
+    type Proof = Vec<[W; N]>;
+    type Error = MerkleTreeError;
+
+    fn commit<M: Matrix<BabyBear>>(&self, inputs: Vec<M>) -> (Self::Commitment, Self::ProverData<M>) {
+        assert_eq!(N, W::DIGEST_ELEMS);
+        // row-major Montgomery words of every matrix (BabyBear is repr(transparent) over u32)
+        let dense: Vec<RowMajorMatrix<BabyBear>> = inputs.iter().map(|m| m.to_row_major_matrix()).collect();
+        let ptrs: Vec<*const u32> = dense.iter().map(|m| m.values.as_ptr() as *const u32).collect();
+        let heights: Vec<usize> = dense.iter().map(|m| m.height()).collect();
+        let widths: Vec<usize> = dense.iter().map(|m| m.width()).collect();
+        let mut root = [0u32; 8];
+        let mut handle: *mut p3hip_tree_t = core::ptr::null_mut();
+        let rc = unsafe {
+            p3hip_mmcs_commit_hash(W::HASH_KIND, ptrs.as_ptr(), heights.as_ptr(), widths.as_ptr(), dense.len(), root.as_mut_ptr(), &mut handle)
+        };
+        // Mmcs::commit is infallible in Plonky3: a device failure is a panic here, caught by the JNI wrapper like any
+        // other prover panic (native/src/lib.rs:45-59)
+        assert!(rc == 0, "hip mmcs commit failed: {}", last_error());
+        let digest: [W; N] = W::from_words(&root).try_into().ok().expect("digest length");
+        (Hash::from(digest), HipTree { handle, mats: inputs, widths })
+    }
+
+    fn open_batch<M: Matrix<BabyBear>>(&self, index: usize, prover_data: &Self::ProverData<M>) -> BatchOpening<BabyBear, Self> {
+        let total: usize = prover_data.widths.iter().sum();
+        let depth = unsafe { p3hip_mmcs_log_max_height(prover_data.handle) };
+        let mut rows = vec![0u32; total.max(1)];
+        let mut path = vec![0u32; (depth * 8).max(8)];
+        let rc = unsafe { p3hip_mmcs_open_batch(prover_data.handle, index, rows.as_mut_ptr(), path.as_mut_ptr(), core::ptr::null_mut()) };
+        assert!(rc == 0, "hip mmcs open_batch failed: {}", last_error());
+        let mut opened_values = Vec::with_capacity(prover_data.widths.len());
+        let mut off = 0;
+        for &w in &prover_data.widths {
+            opened_values.push(rows[off..off + w].iter().map(|v| unsafe { core::mem::transmute::<u32, BabyBear>(*v) }).collect());
+            off += w;
+        }
+        let opening_proof = (0..depth)
+            .map(|l| {
+                let words: [u32; 8] = path[8 * l..8 * l + 8].try_into().unwrap();
+                let d: [W; N] = W::from_words(&words).try_into().ok().expect("digest length");
+                d
+            })
+            .collect();
+        BatchOpening::new(opened_values, opening_proof)
+    }
+
+    fn get_matrices<'a, M: Matrix<BabyBear>>(&self, prover_data: &'a Self::ProverData<M>) -> Vec<&'a M> {
+        prover_data.mats.iter().collect()
+    }
+
+    fn verify_batch(
+        &self,
+        commit: &Self::Commitment,
+        dimensions: &[Dimensions],
+        index: usize,
+        batch_opening: BatchOpeningRef<'_, BabyBear, Self>,
+    ) -> Result<(), Self::Error> {
+        // the verifier side: Plonky3's own CPU code over the same hasher / compressor
+        let (opened_values, opening_proof) = batch_opening.unpack();
+        self.inner.verify_batch(commit, dimensions, index, BatchOpeningRef::new(opened_values, opening_proof))
+    }
+}
+
+/// The reference's hash configuration (native/src/fib_air.rs:28-38), non-hiding: digests `[u64; 4]`.
+pub type HipKeccakMmcs<FieldHash, MyCompress> =
+    HipMmcs<[BabyBear; p3_keccak::VECTOR_LEN], [u64; p3_keccak::VECTOR_LEN], FieldHash, MyCompress, u64, 4>;
+/// north_star's configuration: Poseidon2 sponge 16/8/8 + TruncatedPermutation 2/8/16, digests of 8 field elements.
+pub type HipPoseidon2Mmcs<Sponge, Compress> =
+    HipMmcs<<BabyBear as p3_field::Field>::Packing, <BabyBear as p3_field::Field>::Packing, Sponge, Compress, BabyBear, 8>;

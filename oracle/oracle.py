@@ -311,6 +311,47 @@ def verify_fib_air(proof, a, b, x, log_n, params=None, hash=HASH_POSEIDON2):
                                          C.c_uint64(x), C.c_uint(log_n), *[C.c_uint(v) for v in params.astuple()])
 
 
+def prove_fib_air_hiding(a, b, log_n, params=None, hash=HASH_POSEIDON2, seed=1):
+    """The reference's hiding configuration (fib_air.rs:40-65): MerkleTreeHidingMmcs + HidingFriPcs with
+    SmallRng::seed_from_u64(seed); wire format version 2.  [UPSTREAM-RECALL], parity unpinned."""
+    params = params or FriParams()
+    out = C.POINTER(C.c_uint8)()
+    n = C.c_size_t()
+    L = lib()
+    rc = L.p3o_prove_fib_air_hiding(C.c_int(hash), C.c_uint64(a), C.c_uint64(b), C.c_uint(log_n),
+                                    *[C.c_uint(v) for v in params.astuple()], C.c_uint64(seed), C.byref(out), C.byref(n))
+    if rc:
+        raise ValueError("oracle prove_fib_air_hiding: bad parameters")
+    data = C.string_at(out, n.value)
+    L.p3o_free(out)
+    return data
+
+
+def verify_fib_air_hiding(proof, a, b, x, log_n, params=None, hash=HASH_POSEIDON2):
+    """0 = accept, otherwise the code of the failed check."""
+    params = params or FriParams()
+    buf = (C.c_uint8 * len(proof)).from_buffer_copy(proof)
+    return lib().p3o_verify_fib_air_hiding(C.c_int(hash), buf, C.c_size_t(len(proof)), C.c_uint64(a), C.c_uint64(b),
+                                           C.c_uint64(x), C.c_uint(log_n), *[C.c_uint(v) for v in params.astuple()])
+
+
+def rng_seed_from_u64(seed):
+    s = (C.c_uint64 * 4)()
+    lib().p3o_rng_seed_from_u64(s, C.c_uint64(seed))
+    return s
+
+
+def rng_next_u64(state):
+    lib().p3o_rng_next_u64.restype = C.c_uint64
+    return int(lib().p3o_rng_next_u64(state))
+
+
+def rng_fill_field(state, n):
+    out = np.zeros(max(n, 1), dtype=np.uint32)
+    lib().p3o_rng_fill_field(state, _p(out), C.c_size_t(n))
+    return out[:n]
+
+
 def keccak256(data):
     out = (C.c_uint8 * 32)()
     buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(bytes(data) or b"\0")

@@ -75,6 +75,11 @@ void p3o_keccak_hash_row(const uint32_t *items, size_t n, uint32_t out[8]);
 void p3o_keccak_compress(const uint32_t left[8], const uint32_t right[8], uint32_t out[8]);
 void p3o_keccak256(const uint8_t *in, size_t n, uint8_t out[32]);
 
+/* ---- rng.c: SmallRng::seed_from_u64 (xoshiro256++ / SplitMix64, rand 0.9.2) drawing BabyBear elements ---- */
+void p3o_rng_seed_from_u64(uint64_t s[4], uint64_t seed);
+uint64_t p3o_rng_next_u64(uint64_t s[4]);
+void p3o_rng_fill_field(uint64_t s[4], uint32_t *out, size_t n);
+
 /* ---- stark.c: fib_air prover / verifier (uni-stark + two-adic FRI PCS + duplex challenger) ---- */
 int p3o_prove_fib_air(uint64_t a, uint64_t b, unsigned log_n, unsigned log_blowup, unsigned log_final_poly_len,
                       unsigned num_queries, unsigned pow_bits, uint8_t **out, size_t *out_len);
@@ -86,6 +91,12 @@ int p3o_prove_fib_air_hash(int hash, uint64_t a, uint64_t b, unsigned log_n, uns
                            unsigned num_queries, unsigned pow_bits, uint8_t **out, size_t *out_len);
 int p3o_verify_fib_air_hash(int hash, const uint8_t *proof, size_t len, uint64_t a, uint64_t b, uint64_t x_pub, unsigned log_n,
                             unsigned log_blowup, unsigned log_final_poly_len, unsigned num_queries, unsigned pow_bits);
+/* ---- stark_hiding.c: the HIDING half of the reference's configuration (fib_air.rs:40-65: MerkleTreeHidingMmcs +
+ * HidingFriPcs, SmallRng::seed_from_u64(seed)), for either hash configuration; wire format version 2 ---- */
+int p3o_prove_fib_air_hiding(int hash, uint64_t a, uint64_t b, unsigned log_n, unsigned log_blowup, unsigned log_final_poly_len,
+                             unsigned num_queries, unsigned pow_bits, uint64_t seed, uint8_t **out, size_t *out_len);
+int p3o_verify_fib_air_hiding(int hash, const uint8_t *proof, size_t len, uint64_t a, uint64_t b, uint64_t x_pub, unsigned log_n,
+                              unsigned log_blowup, unsigned log_final_poly_len, unsigned num_queries, unsigned pow_bits);
 void p3o_free(void *p);
 
 #ifdef __cplusplus

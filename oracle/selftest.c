@@ -33,6 +33,23 @@ int main(void) {
                 p3o_free(pf);
             }
         }
+        /* the hiding configuration: prove, verify, truncations, corruptions */
+        for (unsigned log_n = 1; log_n <= 7; log_n += 3) {
+            uint8_t *pf = NULL; size_t len = 0;
+            if (p3o_prove_fib_air_hiding(hash, 2, 3, log_n, 1, 0, 5, 3, 1, &pf, &len)) { printf("hiding prove failed\n"); return 8; }
+            uint64_t l = 2, r = 3;
+            for (uint64_t i = 1; i < (1ull << log_n); i++) { uint64_t t = (l + r) % 0x78000001u; l = r; r = t; }
+            if (p3o_verify_fib_air_hiding(hash, pf, len, 2, 3, r, log_n, 1, 0, 5, 3)) { printf("hiding verify failed\n"); return 9; }
+            for (size_t cut = 0; cut < len; cut += 1 + len / 61)
+                if (!p3o_verify_fib_air_hiding(hash, pf, cut, 2, 3, r, log_n, 1, 0, 5, 3)) { printf("truncated hiding proof accepted\n"); return 10; }
+            for (int k = 0; k < 64; k++) {
+                size_t pos = lcg(&seed) % len;
+                pf[pos] ^= 0x5a;
+                (void)p3o_verify_fib_air_hiding(hash, pf, len, 2, 3, r, log_n, 1, 0, 5, 3);
+                pf[pos] ^= 0x5a;
+            }
+            p3o_free(pf);
+        }
         /* a tree with three height classes and odd widths */
         size_t hs[4] = {64, 64, 16, 1}, ws[4] = {3, 36, 5, 9};
         uint32_t *mats[4];

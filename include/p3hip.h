@@ -182,6 +182,26 @@ int p3hip_fib_prover_create_hash(int hash, unsigned log_n, const p3hip_fri_param
 int p3hip_verify_fib_air_hash(int hash, const uint8_t *proof, size_t len, uint64_t a, uint64_t b, uint64_t x,
                               unsigned log_n, const p3hip_fri_params_t *params);
 
+/* ---- the HIDING half of the reference's configuration (native/src/fib_air.rs:40-65):
+ *      MerkleTreeHidingMmcs<.., SmallRng, .., SALT_ELEMS 4> (rng = SmallRng::seed_from_u64(1)) and
+ *      HidingFriPcs::new(dft, val_mmcs, fri_params, num_random_codewords 4, SmallRng::seed_from_u64(1)), p3_uni_stark with
+ *      SC::Pcs::ZK.  Randomized trace, blinded quotient chunks, randomization polynomial, salted leaves; the random
+ *      streams are generated on the device.  Wire format version 2.  The protocol details are recalled from
+ *      the absent upstream crates: parity unpinned. ---- */
+int p3hip_fib_prover_create_hiding(int hash, unsigned log_n, const p3hip_fri_params_t *params, uint64_t seed, void *stream,
+                                   int own_stream, p3hip_fib_prover_t **out);
+int p3hip_verify_fib_air_hiding(int hash, const uint8_t *proof, size_t len, uint64_t a, uint64_t b, uint64_t x,
+                                unsigned log_n, const p3hip_fri_params_t *params);
+/* rand 0.9.2 `SmallRng::seed_from_u64(seed)` (xoshiro256++ behind SplitMix64) as a device-resident stream of BabyBear
+ * elements (Montgomery words), exactly the sequence a host loop over `rng.random::<BabyBear>()` yields.  One stream is
+ * used from one HIP stream at a time. */
+typedef struct p3hip_rng p3hip_rng_t;
+int p3hip_rng_create(uint64_t seed, p3hip_rng_t **out);
+int p3hip_rng_fill_field_dev(p3hip_rng_t *rng, uint32_t *d_out, size_t n, void *stream);
+/* synchronises `stream` and returns the generator state (s[0..4)) after everything enqueued so far */
+int p3hip_rng_state(p3hip_rng_t *rng, uint64_t state_out[4], void *stream);
+void p3hip_rng_destroy(p3hip_rng_t *rng);
+
 /* ---- batches of independent proofs (BASELINE configs[3]; SURVEY.md §8e: instance i is self-contained) ------
  * A pool of n_provers provers, each on its own host thread (thread-local context, as the reference's runtime,
  * backend_vulkan.rs:100-102) and its own stream, so the transcript round trips of one proof hide behind the

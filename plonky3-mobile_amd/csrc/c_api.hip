@@ -15,6 +15,7 @@
 #include "common.h"
 #include "mmcs.h"
 #include "prover.h"
+#include "rng.h"
 
 namespace p3 {
 bool take_error(std::string* out);
@@ -350,7 +351,8 @@ int p3hip_mmcs_commit_hash(int hash, const uint32_t* const* mats, const size_t* 
 
 // ---- fib_air prover (p3_uni_stark::prove as driven by native/src/fib_air.rs:60-70) ---------------
 struct p3hip_fib_prover {
-    FibProver prover;
+    std::unique_ptr<FibProver> plain;         // TwoAdicFriPcs + MerkleTreeMmcs
+    std::unique_ptr<FibHidingProver> hiding;  // HidingFriPcs + MerkleTreeHidingMmcs (fib_air.rs:40-65)
     std::vector<uint8_t> last;
 };
 
@@ -375,7 +377,8 @@ int p3hip_fib_prover_create_hash(int hash, unsigned log_n, const p3hip_fri_param
         }
         std::unique_ptr<p3hip_fib_prover> p(new p3hip_fib_prover());
         FriParams fp{params->log_blowup, params->log_final_poly_len, params->num_queries, params->proof_of_work_bits};
-        rc = p->prover.init(log_n, fp, st, own, hash);  // on failure the prover's destructor destroys the owned stream
+        p->plain.reset(new FibProver());
+        rc = p->plain->init(log_n, fp, st, own, hash);  // on failure the prover's destructor destroys the owned stream
         if (rc) return rc;
         *out = p.release();
         return OK;
@@ -386,7 +389,7 @@ int p3hip_fib_prover_prove(p3hip_fib_prover_t* prover, uint64_t a, uint64_t b, c
                            size_t* proof_len) {
     return guarded([&]() -> int {
         if (!prover || !proof_out || !proof_len) return fail(ERR_BAD_ARG, "fib_prover_prove: null argument");
-        int rc = prover->prover.prove(a, b, &prover->last);
+        int rc = prover->hiding ? prover->hiding->prove(a, b, &prover->last) : prover->plain->prove(a, b, &prover->last);
         if (rc) return rc;
         *proof_out = prover->last.data();
         *proof_len = prover->last.size();
@@ -396,15 +399,100 @@ int p3hip_fib_prover_prove(p3hip_fib_prover_t* prover, uint64_t a, uint64_t b, c
 
 int p3hip_fib_prover_stage_times(p3hip_fib_prover_t* prover, double out_ms[6], uint64_t* proofs, int reset) {
     if (!prover || !out_ms) return fail(ERR_BAD_ARG, "fib_prover_stage_times: null argument");
-    const StageTimes& t = prover->prover.times();
+    if (!prover->plain) return fail(ERR_BAD_ARG, "fib_prover_stage_times: not kept by the hiding prover");
+    const StageTimes& t = prover->plain->times();
     out_ms[0] = t.trace_commit_ms; out_ms[1] = t.quotient_commit_ms; out_ms[2] = t.open_ms;
     out_ms[3] = t.fri_commit_ms; out_ms[4] = t.grind_ms; out_ms[5] = t.query_ms;
     if (proofs) *proofs = t.proofs;
-    if (reset) prover->prover.reset_times();
+    if (reset) prover->plain->reset_times();
     return OK;
 }
 
 void p3hip_fib_prover_destroy(p3hip_fib_prover_t* prover) { delete prover; }
+
+int p3hip_fib_prover_create_hiding(int hash, unsigned log_n, const p3hip_fri_params_t* params, uint64_t seed, void* stream,
+                                   int own_stream, p3hip_fib_prover_t** out) {
+    return guarded([&]() -> int {
+        if (!params || !out) return fail(ERR_BAD_ARG, "fib_prover_create_hiding: null argument");
+        Context* cx;
+        int rc = get_context(&cx);
+        if (rc) return rc;
+        hipStream_t st = (hipStream_t)stream;
+        bool own = false;
+        if (own_stream) {
+            P3_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            own = true;
+        }
+        std::unique_ptr<p3hip_fib_prover> p(new p3hip_fib_prover());
+        FriParams fp{params->log_blowup, params->log_final_poly_len, params->num_queries, params->proof_of_work_bits};
+        p->hiding.reset(new FibHidingProver());
+        rc = p->hiding->init(log_n, fp, st, own, hash, seed);
+        if (rc) return rc;
+        *out = p.release();
+        return OK;
+    });
+}
+int p3hip_verify_fib_air_hiding(int hash, const uint8_t* proof, size_t len, uint64_t a, uint64_t b, uint64_t x, unsigned log_n,
+                                const p3hip_fri_params_t* params) {
+    return guarded([&]() -> int {
+        if (!proof || !params) return fail(ERR_BAD_ARG, "verify_fib_air_hiding: null argument");
+        FriParams fp{params->log_blowup, params->log_final_poly_len, params->num_queries, params->proof_of_work_bits};
+        std::string why;
+        int rc = verify_fib_air_hiding(proof, len, a, b, x, log_n, fp, &why, hash);
+        if (rc != 0) set_error("fib_air verification failed: " + why);
+        return rc;
+    });
+}
+
+// ---- SmallRng::seed_from_u64 streams on the device (rng.hip) ----
+}  // extern "C"
+struct p3hip_rng {
+    DevRng* d = nullptr;
+    uint32_t* err = nullptr;
+    DevBuf ws;
+    ~p3hip_rng() { if (d) (void)hipFree(d); }
+};
+extern "C" {
+int p3hip_rng_create(uint64_t seed, p3hip_rng_t** out) {
+    return guarded([&]() -> int {
+        if (!out) return fail(ERR_BAD_ARG, "rng_create: null argument");
+        Context* cx;
+        int rc = get_context(&cx);
+        if (rc) return rc;
+        std::unique_ptr<p3hip_rng> r(new p3hip_rng());
+        P3_HIP(hipMalloc(reinterpret_cast<void**>(&r->d), sizeof(DevRng) + 16));
+        r->err = reinterpret_cast<uint32_t*>(r->d + 1);
+        uint64_t s[6] = {0, 0, 0, 0, 0, 0};
+        rng_seed_from_u64(s, seed);
+        P3_HIP(hipMemcpy(r->d, s, sizeof(DevRng) + 16, hipMemcpyHostToDevice));
+        *out = r.release();
+        return OK;
+    });
+}
+int p3hip_rng_fill_field_dev(p3hip_rng_t* rng, uint32_t* d_out, size_t n, void* stream) {
+    return guarded([&]() -> int {
+        if (!rng || (n && !d_out)) return fail(ERR_BAD_ARG, "rng_fill_field: null argument");
+        Context* cx;
+        int rc = get_context(&cx);
+        if (rc) return rc;
+        size_t words = 0;
+        if ((rc = rng_workspace_words(n, &words))) return rc;
+        if ((rc = rng->ws.reserve(words * 4))) return rc;
+        return rng_fill_field(*cx, (hipStream_t)stream, rng->d, d_out, n, rng->ws.as<uint32_t>(), rng->err);
+    });
+}
+int p3hip_rng_state(p3hip_rng_t* rng, uint64_t state_out[4], void* stream) {
+    return guarded([&]() -> int {
+        if (!rng || !state_out) return fail(ERR_BAD_ARG, "rng_state: null argument");
+        uint64_t s[6];
+        P3_HIP(hipMemcpyAsync(s, rng->d, sizeof(DevRng) + 16, hipMemcpyDeviceToHost, (hipStream_t)stream));
+        P3_HIP(hipStreamSynchronize((hipStream_t)stream));
+        memcpy(state_out, s, 32);
+        if ((uint32_t)s[4] != 0) return fail(ERR_INTERNAL, "rng: a fill ran out of raw draws");
+        return OK;
+    });
+}
+void p3hip_rng_destroy(p3hip_rng_t* rng) { delete rng; }
 
 int p3hip_verify_fib_air(const uint8_t* proof, size_t len, uint64_t a, uint64_t b, uint64_t x, unsigned log_n,
                          const p3hip_fri_params_t* params) {

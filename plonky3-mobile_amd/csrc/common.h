@@ -64,6 +64,7 @@ struct Context {
     std::map<std::tuple<uint32_t, uint32_t, uint32_t>, CachedTable> scale_tables;  // (base, log_n, mult)
     std::map<std::pair<hipStream_t, int>, DevBuf> scratch;                         // (stream, slot)
     std::set<const void*> attr_done;  // kernels whose dynamic-LDS limit has been raised on this device
+    uint64_t* rng_jump = nullptr;  // rng.hip: GF(2) jump matrices of the xoshiro256++ state transition
     std::map<uint32_t, CachedTable> selector_tables;  // prover.hip: log_n -> selectors on the quotient coset (t.lo)
     int init(int dev);
     // scratch slab `slot` of the calling thread for work enqueued on `stream`

@@ -183,6 +183,7 @@ Context::~Context() {
     for (auto& kv : scale_tables) free_table(kv.second);
     for (auto& kv : selector_tables) free_table(kv.second);
     for (int i = 0; i < 2; i++) if (tile_tw[i]) (void)hipFree(tile_tw[i]);
+    if (rng_jump) (void)hipFree(rng_jump);
 }
 
 // One context per device the thread has used.  Leaked at thread exit on purpose (HIP may already be torn down when

@@ -34,8 +34,26 @@ class FibProver {
     Impl* im;
 };
 
+// The same prover for the HIDING half of the reference's configuration (native/src/fib_air.rs:40-65:
+// MerkleTreeHidingMmcs + HidingFriPcs, SmallRng::seed_from_u64(seed)); wire format version 2 (prover_hiding.inc).
+class FibHidingProver {
+  public:
+    FibHidingProver();
+    ~FibHidingProver();
+    FibHidingProver(const FibHidingProver&) = delete;
+    int init(uint32_t log_n, const FriParams& fp, hipStream_t stream, bool own_stream, int hash, uint64_t seed);
+    int prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof);
+
+  private:
+    struct Impl;
+    Impl* im;
+};
+
 // verifier.hip: p3_uni_stark::verify for FibonacciAir on the host (0 = accept, else the failed check's code)
 int verify_fib_air(const uint8_t* proof, size_t len, uint64_t a_pub, uint64_t b_pub, uint64_t x_pub, uint32_t log_n,
                    const FriParams& fp, std::string* why, int hash = 0);
+// the verifier of hiding proofs (wire format version 2)
+int verify_fib_air_hiding(const uint8_t* proof, size_t len, uint64_t a_pub, uint64_t b_pub, uint64_t x_pub, uint32_t log_n,
+                          const FriParams& fp, std::string* why, int hash);
 
 }  // namespace p3

@@ -23,6 +23,7 @@
 #include "poseidon2.cuh"
 #include "poseidon2_f64.cuh"
 #include "prover.h"
+#include "rng.h"
 #include "transcript.cuh"
 
 namespace p3 {
@@ -893,3 +894,5 @@ const StageTimes& FibProver::times() const { return im->times; }
 void FibProver::reset_times() { im->times = StageTimes{}; }
 
 }  // namespace p3
+
+#include "prover_hiding.inc"

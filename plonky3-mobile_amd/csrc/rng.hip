@@ -1,0 +1,202 @@
+// The random streams of the reference's hiding configuration, generated ON THE DEVICE with the exact sequential
+// semantics of the host generator: `SmallRng::seed_from_u64(1)` (native/src/fib_air.rs:50,65) = xoshiro256++ seeded
+// through SplitMix64 (rand 0.9.2, absent: restated from the published algorithms), BabyBear elements drawn by
+// rejection of 31-bit words (p3-monty-31's StandardUniform: v = next_u32() >> 1, accepted when v < P, used as the
+// Montgomery word) [UPSTREAM-RECALL for the sampling convention].
+//
+// A sequential generator with data-dependent rejections, in parallel:
+//   - the state transition of xoshiro256++ is linear over GF(2), so "advance by m steps" is a 256 x 256 bit matrix;
+//     the host builds J_k = T^(CHUNK * 2^k) once, lane t reaches the start of its chunk of CHUNK raw draws by
+//     applying J_k for the set bits of t (uniform loop, scalar matrix loads, per-lane select);
+//   - pass 1 counts the accepted draws of every chunk, a one-workgroup scan turns the counts into output offsets,
+//     pass 2 replays the chunks and writes the accepted values to their places; the lane that writes the n-th value
+//     also writes the generator state right after that draw back to the stream, so the next fill continues exactly
+//     where a host loop would.
+// Nothing synchronises with the host.  A fill that runs out of raw draws (probability far below 2^-100 with the margin
+// used) raises the error word instead of producing a short stream.
+#include "bb31.cuh"
+#include "common.h"
+#include "rng.h"
+
+#include <memory>
+#include <mutex>
+
+namespace p3 {
+
+constexpr uint32_t RNG_CHUNK_LOG = 10, RNG_CHUNK = 1u << RNG_CHUNK_LOG;  // raw draws per lane
+constexpr uint32_t RNG_MAX_JUMP = 20;                                     // up to 2^20 chunks per fill
+
+// ---- host: SplitMix64 seeding and the GF(2) jump matrices ----
+void rng_seed_from_u64(uint64_t s[4], uint64_t state) {
+    for (int i = 0; i < 4; i++) {
+        state += 0x9e3779b97f4a7c15ULL;
+        uint64_t z = state;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+        s[i] = z ^ (z >> 31);
+    }
+}
+__host__ __device__ __forceinline__ uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+__host__ __device__ __forceinline__ uint64_t xoshiro_next(uint64_t (&s)[4]) {
+    const uint64_t result = rotl64(s[0] + s[3], 23) + s[0];
+    const uint64_t t = s[1] << 17;
+    s[2] ^= s[0];
+    s[3] ^= s[1];
+    s[1] ^= s[2];
+    s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl64(s[3], 45);
+    return result;
+}
+
+namespace {
+struct Bits256 { uint64_t w[4]; };
+struct Mat256 { Bits256 col[256]; };  // M v = xor of col[j] over the set bits j of v
+Bits256 matvec(const Mat256& m, const Bits256& v) {
+    Bits256 r{{0, 0, 0, 0}};
+    for (int j = 0; j < 256; j++)
+        if ((v.w[j >> 6] >> (j & 63)) & 1)
+            for (int k = 0; k < 4; k++) r.w[k] ^= m.col[j].w[k];
+    return r;
+}
+void matsquare(const Mat256& m, Mat256* out) {
+    for (int j = 0; j < 256; j++) out->col[j] = matvec(m, m.col[j]);
+}
+// J[k] = T^(RNG_CHUNK * 2^k), T = one state transition; built once per process
+const std::vector<uint64_t>& jump_matrices() {
+    static std::vector<uint64_t> flat;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        std::unique_ptr<Mat256> a(new Mat256()), b(new Mat256());
+        for (int j = 0; j < 256; j++) {
+            uint64_t s[4] = {0, 0, 0, 0};
+            s[j >> 6] = 1ull << (j & 63);
+            (void)xoshiro_next(s);
+            for (int k = 0; k < 4; k++) a->col[j].w[k] = s[k];
+        }
+        for (uint32_t i = 0; i < RNG_CHUNK_LOG; i++) { matsquare(*a, b.get()); a.swap(b); }
+        flat.resize((size_t)RNG_MAX_JUMP * 256 * 4);
+        for (uint32_t k = 0; k < RNG_MAX_JUMP; k++) {
+            for (int j = 0; j < 256; j++)
+                for (int w = 0; w < 4; w++) flat[((size_t)k * 256 + j) * 4 + w] = a->col[j].w[w];
+            matsquare(*a, b.get());
+            a.swap(b);
+        }
+    });
+    return flat;
+}
+}  // namespace
+
+// ---- device ----
+__global__ void __launch_bounds__(256) rng_pass1_kernel(const DevRng* st, const uint64_t* __restrict__ jump, uint32_t n_chunks,
+                                                        uint32_t n_bits, uint64_t* states, uint32_t* counts) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t s[4] = {st->s[0], st->s[1], st->s[2], st->s[3]};
+    for (uint32_t k = 0; k < n_bits; k++) {  // uniform loop: every lane multiplies, lanes whose bit k is clear keep s
+        uint64_t r[4] = {0, 0, 0, 0};
+        const uint64_t* m = jump + (size_t)k * 256 * 4;
+#pragma unroll
+        for (int sw = 0; sw < 4; sw++) {
+            const uint64_t word = s[sw];
+            for (uint32_t b = 0; b < 64; b++) {
+                const uint64_t mask = 0ull - ((word >> b) & 1ull);
+                const uint64_t* col = m + ((size_t)sw * 64 + b) * 4;
+#pragma unroll
+                for (int w = 0; w < 4; w++) r[w] ^= col[w] & mask;
+            }
+        }
+        if ((t >> k) & 1u) { s[0] = r[0]; s[1] = r[1]; s[2] = r[2]; s[3] = r[3]; }
+    }
+    if (t >= n_chunks) return;
+#pragma unroll
+    for (int w = 0; w < 4; w++) states[(size_t)t * 4 + w] = s[w];
+    uint32_t cnt = 0;
+    for (uint32_t i = 0; i < RNG_CHUNK; i++) cnt += ((uint32_t)(xoshiro_next(s) >> 32) >> 1) < bb::P ? 1u : 0u;
+    counts[t] = cnt;
+}
+// exclusive scan of counts[0..n) in place (one workgroup)
+__global__ void __launch_bounds__(1024) rng_scan_kernel(uint32_t* counts, uint32_t n) {
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (n + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += counts[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
+    for (uint32_t i = lo; i < hi; i++) { uint32_t c = counts[i]; counts[i] = run; run += c; }
+}
+__global__ void __launch_bounds__(256) rng_pass2_kernel(DevRng* st, const uint64_t* states, const uint32_t* offsets, uint32_t n_chunks,
+                                                        uint32_t* out, uint64_t n, uint32_t* err) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_chunks) return;
+    uint64_t s[4] = {states[(size_t)t * 4], states[(size_t)t * 4 + 1], states[(size_t)t * 4 + 2], states[(size_t)t * 4 + 3]};
+    uint64_t pos = offsets[t];
+    if (pos >= n) return;  // the stream was complete before this chunk
+    for (uint32_t i = 0; i < RNG_CHUNK; i++) {
+        const uint32_t v = (uint32_t)(xoshiro_next(s) >> 32) >> 1;
+        if (v < bb::P) {
+            out[pos++] = v;
+            if (pos == n) {  // the n-th element: the stream continues right after this draw
+#pragma unroll
+                for (int w = 0; w < 4; w++) st->s[w] = s[w];
+                return;
+            }
+        }
+    }
+    if (t + 1 == n_chunks) atomicOr(err, 1u);  // ran out of raw draws (never, with the margin of rng_fill_field)
+}
+
+__global__ void rng_set_kernel(DevRng* st, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
+    st->s[0] = a; st->s[1] = b; st->s[2] = c; st->s[3] = d;
+}
+
+int rng_seed(hipStream_t stream, DevRng* st, uint64_t seed) {
+    uint64_t s[4];
+    rng_seed_from_u64(s, seed);
+    hipLaunchKernelGGL(rng_set_kernel, dim3(1), dim3(1), 0, stream, st, s[0], s[1], s[2], s[3]);
+    P3_HIP(hipGetLastError());
+    return OK;
+}
+
+int rng_workspace_words(uint64_t n_max, size_t* words) {
+    const uint64_t raw = n_max + n_max / 8 + 64 * (uint64_t)RNG_CHUNK;
+    const uint64_t chunks = (raw + RNG_CHUNK - 1) / RNG_CHUNK;
+    if (chunks >> RNG_MAX_JUMP) return fail(ERR_BAD_ARG, "rng: fill too large");
+    *words = (size_t)chunks * 8 + (size_t)chunks + 16;  // states (4 x u64) + counts
+    return OK;
+}
+
+int rng_fill_field(Context& cx, hipStream_t stream, DevRng* st, uint32_t* out, uint64_t n, uint32_t* workspace, uint32_t* err) {
+    if (!n) return OK;
+    // jump matrices: one copy per (thread, device) context
+    if (!cx.rng_jump) {
+        const std::vector<uint64_t>& j = jump_matrices();
+        P3_HIP(hipMalloc(reinterpret_cast<void**>(&cx.rng_jump), j.size() * 8));
+        P3_HIP(hipMemcpy(cx.rng_jump, j.data(), j.size() * 8, hipMemcpyHostToDevice));
+    }
+    // raw draws: n / (P / 2^31) = n * 1.0667 expected; 12.5 % + 64 chunks of margin is > 50 standard deviations
+    const uint64_t raw = n + n / 8 + 64 * (uint64_t)RNG_CHUNK;
+    const uint64_t chunks64 = (raw + RNG_CHUNK - 1) / RNG_CHUNK;
+    if (chunks64 >> RNG_MAX_JUMP) return fail(ERR_BAD_ARG, "rng: fill too large");
+    const uint32_t chunks = (uint32_t)chunks64;
+    uint32_t n_bits = 0;
+    while ((1u << n_bits) < chunks) n_bits++;
+    uint64_t* states = reinterpret_cast<uint64_t*>(workspace);
+    uint32_t* counts = workspace + (size_t)chunks * 8;
+    const uint32_t blocks = (chunks + 255) / 256;
+    hipLaunchKernelGGL(rng_pass1_kernel, dim3(blocks), dim3(256), 0, stream, st, cx.rng_jump, chunks, n_bits, states, counts);
+    P3_HIP(hipGetLastError());
+    hipLaunchKernelGGL(rng_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, chunks);
+    P3_HIP(hipGetLastError());
+    hipLaunchKernelGGL(rng_pass2_kernel, dim3(blocks), dim3(256), 0, stream, st, states, counts, chunks, out, n, err);
+    P3_HIP(hipGetLastError());
+    return OK;
+}
+
+}  // namespace p3

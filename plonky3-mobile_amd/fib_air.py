@@ -42,14 +42,20 @@ class FibAirProver:
     """prove(&config, &FibonacciAir{}, generate_trace_rows(a, b, 2^log_n), &[a, b, x]) (fib_air.rs:61-70)
     on the hip backend.  One instance = one HBM arena + one stream; use one per host thread."""
 
-    def __init__(self, log_n, log_blowup=1, params=None, own_stream=True, hash="poseidon2"):
+    def __init__(self, log_n, log_blowup=1, params=None, own_stream=True, hash="poseidon2", hiding=False, seed=1):
         """hash="keccak": the reference's own hash configuration (fib_air.rs:28-53: Keccak MMCS +
-        SerializingChallenger32 over a Keccak-256 HashChallenger), non-hiding."""
+        SerializingChallenger32 over a Keccak-256 HashChallenger).  hiding=True: the reference's MerkleTreeHidingMmcs +
+        HidingFriPcs with both SmallRng streams seeded by `seed` (fib_air.rs:40-65; wire format version 2)."""
         self.params = params or FriParameters(log_blowup=log_blowup)
         self.log_n = log_n
         self.hash = hash
+        self.hiding = hiding
         self._h = C.c_void_p()
         stream = None if own_stream else _stream_ptr()
+        if hiding:
+            _lib.check(_lib.lib().p3hip_fib_prover_create_hiding(_hash_kind(hash), log_n, C.cast(self.params._c(), C.c_void_p), seed,
+                                                                 stream, 1 if own_stream else 0, C.byref(self._h)))
+            return
         _lib.check(_lib.lib().p3hip_fib_prover_create_hash(_hash_kind(hash), log_n, C.cast(self.params._c(), C.c_void_p),
                                                            stream, 1 if own_stream else 0, C.byref(self._h)))
 
@@ -196,28 +202,60 @@ def fib_public_x(a, b, n):
     return r
 
 
-def verify_fib_air(proof, a, b, x, log_n, params=None, hash="poseidon2"):
+def verify_fib_air(proof, a, b, x, log_n, params=None, hash="poseidon2", hiding=False):
     """verify(&config, &FibonacciAir{}, &proof, &[a, b, x]) (fib_air.rs:71-72), host side.  Raises
     P3HipError("fib_air verification failed: <check>") on rejection, like the reference's map_err."""
     params = params or FriParameters()
     buf = (C.c_uint8 * len(proof)).from_buffer_copy(proof)
-    _lib.check(_lib.lib().p3hip_verify_fib_air_hash(_hash_kind(hash), buf, len(proof), a, b, x, log_n,
-                                                    C.cast(params._c(), C.c_void_p)))
+    fn = _lib.lib().p3hip_verify_fib_air_hiding if hiding else _lib.lib().p3hip_verify_fib_air_hash
+    _lib.check(fn(_hash_kind(hash), buf, len(proof), a, b, x, log_n, C.cast(params._c(), C.c_void_p)))
 
 
-def run_fib_air(log_n=3, a=0, b=1, params=None, hash="poseidon2"):
+def run_fib_air(log_n=3, a=0, b=1, params=None, hash="poseidon2", hiding=False, seed=1):
     """run_fib_air_zk (fib_air.rs:27-75) on the hip backend: prove, verify, report.  Default n = 8, x = 21 as in the
-    reference (fib_air.rs:56-57).  hash="keccak" selects the reference's own hashes (non-hiding)."""
+    reference (fib_air.rs:56-57).  hash="keccak", hiding=True is the reference's own configuration: Keccak hashes,
+    MerkleTreeHidingMmcs and HidingFriPcs with SmallRng::seed_from_u64(1) (fib_air.rs:28-65)."""
     params = params or FriParameters()
     n = 1 << log_n
     x = fib_public_x(a, b, n)
-    prover = FibAirProver(log_n, params=params, hash=hash)
+    prover = FibAirProver(log_n, params=params, hash=hash, hiding=hiding, seed=seed)
     try:
         proof = prover.prove(a, b)
     finally:
         prover.close()
-    verify_fib_air(proof, a, b, x, log_n, params, hash=hash)
-    return "fib_air ok (n=%d, x=%d)" % (n, x)
+    verify_fib_air(proof, a, b, x, log_n, params, hash=hash, hiding=hiding)
+    return "fib_air %sok (n=%d, x=%d)" % ("zk " if hiding else "", n, x)
+
+
+class DeviceRng:
+    """rand 0.9.2 `SmallRng::seed_from_u64(seed)` as a device-resident stream of BabyBear elements (rng.hip)."""
+
+    def __init__(self, seed=1):
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().p3hip_rng_create(seed, C.byref(self._h)))
+
+    def fill_field(self, n):
+        """The next n elements of the stream as an int32 CUDA tensor of Montgomery words (enqueued on the current stream)."""
+        import torch
+        out = torch.empty((max(n, 1),), dtype=torch.int32, device="cuda")
+        _lib.check(_lib.lib().p3hip_rng_fill_field_dev(self._h, C.c_void_p(out.data_ptr()), n, _stream_ptr()))
+        return out[:n]
+
+    def state(self):
+        s = (C.c_uint64 * 4)()
+        _lib.check(_lib.lib().p3hip_rng_state(self._h, s, _stream_ptr()))
+        return list(s)
+
+    def close(self):
+        if self._h:
+            _lib.lib().p3hip_rng_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class FibAirBatchProver:

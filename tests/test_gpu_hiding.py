@@ -1,0 +1,81 @@
+"""GPU parity tests of the HIDING half of the reference's configuration (native/src/fib_air.rs:40-65): the device-resident
+SmallRng streams, and the hiding prover whose proofs (randomized trace, blinded quotient chunks, randomization
+polynomial, salted leaves) must equal the CPU oracle's byte for byte under both hash configurations.  Upstream parity of
+the protocol is unpinned (oracle/stark_hiding.c); the generator itself is pinned (tests/test_oracle_hiding.py)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [1, 0xDEADBEEF])
+def test_device_rng_stream_equals_host_stream(p3, oracle, seed):
+    """Fills of many sizes back to back: every element and the generator state afterwards equal a sequential host loop
+    (the rejections make positions data-dependent; chunk boundaries at 1024 raw draws are crossed on purpose)."""
+    import torch
+    ok, msg = p3.is_available()
+    assert ok, msg
+    rng = p3.DeviceRng(seed)
+    host = oracle.rng_seed_from_u64(seed)
+    for n in [1, 3, 959, 960, 961, 1024, 5000, 0, 70001, 1 << 20, 17]:
+        got = rng.fill_field(n)
+        torch.cuda.synchronize()
+        exp = oracle.rng_fill_field(host, n)
+        assert np.array_equal(p3.host_u32(got), exp), n
+        assert rng.state() == list(host), n
+    rng.close()
+
+
+def _fp(p3, oracle, *t):
+    return p3.FriParameters(*t), oracle.FriParams(*t)
+
+
+@pytest.mark.parametrize("hash", ["poseidon2", "keccak"])
+@pytest.mark.parametrize("log_n,t", [(1, (1, 0, 4, 2)), (3, (2, 2, 2, 1)), (6, (1, 0, 9, 5)), (10, (1, 0, 12, 8)), (12, (2, 1, 6, 6))])
+def test_hiding_proof_bytes_equal_oracle(p3, oracle, hash, log_n, t):
+    gfp, ofp = _fp(p3, oracle, *t)
+    kind = oracle.HASH_KECCAK if hash == "keccak" else oracle.HASH_POSEIDON2
+    pr = p3.FibAirProver(log_n, params=gfp, hash=hash, hiding=True, seed=1)
+    for a, b in [(0, 1), (5, 9)]:
+        proof = pr.prove(a, b)
+        ref = oracle.prove_fib_air_hiding(a, b, log_n, ofp, hash=kind, seed=1)
+        assert len(proof) == len(ref)
+        if proof != ref:
+            w1, w2 = np.frombuffer(proof, np.uint32), np.frombuffer(ref, np.uint32)
+            first = int(np.nonzero(w1 != w2)[0][0])
+            pytest.fail("proof words differ first at %d of %d" % (first, len(w1)))
+        x = oracle.fib_public_x(a, b, 1 << log_n)
+        assert oracle.verify_fib_air_hiding(proof, a, b, x, log_n, ofp, hash=kind) == 0
+        p3.verify_fib_air(proof, a, b, x, log_n, gfp, hash=hash, hiding=True)  # the product's own host verifier
+    pr.close()
+
+
+def test_reference_configuration_end_to_end(p3, oracle):
+    """run_fib_air_zk as the reference wires it (fib_air.rs:27-75): Keccak hashes, hiding MMCS and PCS seeded with 1,
+    create_test_fri_params(mmcs, 2), n = 8, x = 21 — prove on the device, verify on the host, report."""
+    gfp, ofp = _fp(p3, oracle, 2, 2, 2, 1)
+    assert p3.run_fib_air(log_n=3, params=gfp, hash="keccak", hiding=True) == "fib_air zk ok (n=8, x=21)"
+    proof = p3.FibAirProver(3, params=gfp, hash="keccak", hiding=True).prove(0, 1)
+    assert proof == oracle.prove_fib_air_hiding(0, 1, 3, ofp, hash=oracle.HASH_KECCAK, seed=1)
+    with pytest.raises(p3.P3HipError):
+        p3.verify_fib_air(proof, 0, 1, 22, 3, gfp, hash="keccak", hiding=True)
+
+
+def test_hiding_seed_changes_the_proof_not_the_statement(p3, oracle):
+    gfp, ofp = _fp(p3, oracle, 1, 0, 8, 4)
+    p1 = p3.FibAirProver(8, params=gfp, hiding=True, seed=1).prove(0, 1)
+    p2 = p3.FibAirProver(8, params=gfp, hiding=True, seed=2).prove(0, 1)
+    x = oracle.fib_public_x(0, 1, 256)
+    assert p1 != p2
+    assert oracle.verify_fib_air_hiding(p1, 0, 1, x, 8, ofp) == 0 and oracle.verify_fib_air_hiding(p2, 0, 1, x, 8, ofp) == 0
+    assert p2 == oracle.prove_fib_air_hiding(0, 1, 8, ofp, seed=2)
+
+
+def test_hiding_headline_size_verifies(p3, oracle):
+    """2^18-row trace (randomized to 2^19, LDE 2^20), benchmark FRI parameters: the oracle's verifier accepts."""
+    gfp, ofp = _fp(p3, oracle, 1, 0, 100, 16)
+    pr = p3.FibAirProver(18, params=gfp, hiding=True)
+    proof = pr.prove(0, 1)
+    assert oracle.verify_fib_air_hiding(proof, 0, 1, oracle.fib_public_x(0, 1, 1 << 18), 18, ofp) == 0
+    assert pr.prove(0, 1) == proof
+    pr.close()

@@ -139,3 +139,24 @@ def test_header_is_plain_c(tmp_path):
     r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
                         "-fsyntax-only", str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_product_hiding_verifier_accepts_oracle_proofs_and_rejects_tampering(p3, oracle):
+    """p3hip_verify_fib_air_hiding is host code: cross-check it against the oracle's hiding prover (both hash
+    configurations) and against tampered proofs."""
+    import numpy as np
+    for hash, kind in (("poseidon2", 0), ("keccak", 1)):
+        for log_n, t in [(3, (2, 2, 2, 1)), (6, (1, 0, 7, 4))]:
+            gfp, ofp = p3.FriParameters(*t), oracle.FriParams(*t)
+            proof = oracle.prove_fib_air_hiding(2, 3, log_n, ofp, hash=kind)
+            x = oracle.fib_public_x(2, 3, 1 << log_n)
+            p3.verify_fib_air(proof, 2, 3, x, log_n, gfp, hash=hash, hiding=True)
+            with pytest.raises(p3.P3HipError):
+                p3.verify_fib_air(proof, 2, 3, x + 1, log_n, gfp, hash=hash, hiding=True)
+            words = np.frombuffer(proof, np.uint32)
+            rng = np.random.default_rng(log_n)
+            for pos in rng.choice(len(words), size=25, replace=False):
+                bad = words.copy()
+                bad[pos] = (int(bad[pos]) + 1) % 0x78000001
+                with pytest.raises(p3.P3HipError):
+                    p3.verify_fib_air(bad.tobytes(), 2, 3, x, log_n, gfp, hash=hash, hiding=True)

@@ -201,6 +201,12 @@ int p3hip_rng_fill_field_dev(p3hip_rng_t *rng, uint32_t *d_out, size_t n, void *
 /* synchronises `stream` and returns the generator state (s[0..4)) after everything enqueued so far */
 int p3hip_rng_state(p3hip_rng_t *rng, uint64_t state_out[4], void *stream);
 void p3hip_rng_destroy(p3hip_rng_t *rng);
+/* MerkleTreeHidingMmcs::commit (native/src/fib_air.rs:40-51, SALT_ELEMS = 4): every matrix is paired with a
+ * height x 4 matrix of draws from `rng` (in input order), leaf rows are m0 || s0 || m1 || s1 ...; the tree owns the salt
+ * matrices.  p3hip_mmcs_open_batch on such a tree returns the rows in that interleaved order (2 n_mats entries: the
+ * caller splits values from salts, as MerkleTreeHidingMmcs::open_batch does); root / layers / free are shared. */
+int p3hip_mmcs_commit_hiding_dev(int hash, const uint32_t *const *d_mats, const size_t *heights, const size_t *widths,
+                                 size_t n_mats, p3hip_rng_t *rng, uint32_t root_out[8], p3hip_tree_t **tree_out, void *stream);
 
 /* ---- batches of independent proofs (BASELINE configs[3]; SURVEY.md §8e: instance i is self-contained) ------
  * A pool of n_provers provers, each on its own host thread (thread-local context, as the reference's runtime,

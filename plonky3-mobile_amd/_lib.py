@@ -66,6 +66,8 @@ _SIGS = {
     "p3hip_rng_fill_field_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "p3hip_rng_state": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]),
     "p3hip_rng_destroy": (None, [C.c_void_p]),
+    "p3hip_mmcs_commit_hiding_dev": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
+                                               C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
     "p3hip_fib_batch_create": (C.c_int, [C.c_uint, C.c_void_p, C.c_uint, C.POINTER(C.c_void_p)]),
     "p3hip_fib_batch_create_hash": (C.c_int, [C.c_int, C.c_uint, C.c_void_p, C.c_uint, C.POINTER(C.c_void_p)]),
     "p3hip_fib_batch_prove": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),

@@ -494,6 +494,34 @@ int p3hip_rng_state(p3hip_rng_t* rng, uint64_t state_out[4], void* stream) {
 }
 void p3hip_rng_destroy(p3hip_rng_t* rng) { delete rng; }
 
+// MerkleTreeHidingMmcs::commit (fib_air.rs:40-51): every matrix is paired with a height x SALT_ELEMS matrix of draws
+// from the MMCS's rng; leaf rows are m0 || s0 || m1 || s1 ...  The salt matrices live in HBM and belong to the tree.
+int p3hip_mmcs_commit_hiding_dev(int hash, const uint32_t* const* d_mats, const size_t* heights, const size_t* widths, size_t n_mats,
+                                 p3hip_rng_t* rng, uint32_t root_out[8], p3hip_tree_t** tree_out, void* stream) {
+    return guarded([&]() -> int {
+        if (!d_mats || !heights || !widths || !n_mats || !rng || !root_out || !tree_out) return fail(ERR_BAD_ARG, "mmcs_commit_hiding: null/empty argument");
+        if (n_mats > 32) return fail(ERR_BAD_ARG, "mmcs_commit_hiding: at most 32 matrices per commitment");
+        constexpr size_t SALT = 4;
+        std::vector<void*> owned;
+        auto cleanup = [&]() { for (void* p : owned) (void)hipFree(p); };
+        std::vector<const uint32_t*> mp;
+        std::vector<size_t> hh, ww;
+        for (size_t i = 0; i < n_mats; i++) {
+            void* salt = nullptr;
+            if (hipMalloc(&salt, heights[i] * SALT * 4 + 16) != hipSuccess) { cleanup(); return fail(ERR_HIP, "hipMalloc failed"); }
+            owned.push_back(salt);
+            int rc = p3hip_rng_fill_field_dev(rng, (uint32_t*)salt, heights[i] * SALT, stream);
+            if (rc) { cleanup(); return rc; }
+            mp.push_back(d_mats[i]); hh.push_back(heights[i]); ww.push_back(widths[i]);
+            mp.push_back((const uint32_t*)salt); hh.push_back(heights[i]); ww.push_back(SALT);
+        }
+        int rc = p3hip_mmcs_commit_hash_dev(hash, mp.data(), hh.data(), ww.data(), mp.size(), root_out, tree_out, stream);
+        if (rc) { cleanup(); return rc; }
+        (*tree_out)->t->owned = owned;
+        return OK;
+    });
+}
+
 int p3hip_verify_fib_air(const uint8_t* proof, size_t len, uint64_t a, uint64_t b, uint64_t x, unsigned log_n,
                          const p3hip_fri_params_t* params) {
     return p3hip_verify_fib_air_hash(HASH_POSEIDON2, proof, len, a, b, x, log_n, params);

@@ -120,3 +120,45 @@ class MerkleTreeMmcs:
             out.append(rows[off:off + m.shape[1]].copy())
             off += m.shape[1]
         return out, path[: tree.log_max_height].copy()
+
+
+class MerkleTreeHidingMmcs(MerkleTreeMmcs):
+    """MerkleTreeHidingMmcs<.., SmallRng, .., SALT_ELEMS 4> (native/src/fib_air.rs:40-51): commit salts every matrix with
+    draws from the MMCS's own rng (a DeviceRng: the stream lives in HBM); open_batch returns (values, (salts, siblings))."""
+    SALT_ELEMS = 4
+
+    def __init__(self, hash="keccak", rng=None, seed=1):
+        super().__init__(hash)
+        from .fib_air import DeviceRng
+        self.rng = rng or DeviceRng(seed)
+
+    def commit(self, mats):
+        import torch
+        L = _lib.lib()
+        dmats = [m.contiguous() if _is_torch(m) else dev_u32(m) for m in mats]
+        n = len(dmats)
+        ptrs = (C.c_void_p * n)(*[m.data_ptr() for m in dmats])
+        hs = (C.c_size_t * n)(*[m.shape[0] for m in dmats])
+        ws = (C.c_size_t * n)(*[m.shape[1] for m in dmats])
+        root = np.zeros(8, dtype=np.uint32)
+        handle = C.c_void_p()
+        torch.cuda.current_stream()
+        _lib.check(L.p3hip_mmcs_commit_hiding_dev(self._kind, ptrs, hs, ws, n, self.rng._h, root.ctypes.data_as(C.c_void_p),
+                                                  C.byref(handle), _stream_ptr()))
+        return root, MerkleTree(handle, dmats, root)
+
+    def open_batch(self, index, tree):
+        n = len(tree.mats)
+        tot = sum(m.shape[1] + self.SALT_ELEMS for m in tree.mats)
+        rows = np.zeros(tot, dtype=np.uint32)
+        path = np.zeros((max(tree.log_max_height, 1), 8), dtype=np.uint32)
+        _lib.check(_lib.lib().p3hip_mmcs_open_batch(tree._h, index, rows.ctypes.data_as(C.c_void_p),
+                                                    path.ctypes.data_as(C.c_void_p), _stream_ptr()))
+        vals, salts, off = [], [], 0
+        for m in tree.mats:
+            w = m.shape[1]
+            vals.append(rows[off:off + w].copy())
+            salts.append(rows[off + w:off + w + self.SALT_ELEMS].copy())
+            off += w + self.SALT_ELEMS
+        assert len(vals) == n
+        return vals, (salts, path[: tree.log_max_height].copy())

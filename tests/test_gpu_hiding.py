@@ -79,3 +79,29 @@ def test_hiding_headline_size_verifies(p3, oracle):
     assert oracle.verify_fib_air_hiding(proof, 0, 1, oracle.fib_public_x(0, 1, 1 << 18), 18, ofp) == 0
     assert pr.prove(0, 1) == proof
     pr.close()
+
+
+@pytest.mark.parametrize("hash", ["poseidon2", "keccak"])
+def test_hiding_mmcs_commit_and_openings(p3, oracle, hash):
+    """MerkleTreeHidingMmcs on the device: salts drawn from the MMCS's own stream in input order, leaves m0 || s0 || m1 || s1;
+    root and openings equal the oracle tree over the same interleaved (matrix, salt) list; two commits continue the stream."""
+    rng = np.random.default_rng(9)
+    kind = oracle.HASH_KECCAK if hash == "keccak" else oracle.HASH_POSEIDON2
+    mmcs = p3.MerkleTreeHidingMmcs(hash, seed=1)
+    host = oracle.rng_seed_from_u64(1)
+    for mats_shape in ([(64, 6)], [(128, 4), (128, 4), (32, 3)]):
+        mats = [rng.integers(0, 0x78000001, size=s, dtype=np.uint64).astype(np.uint32) for s in mats_shape]
+        root, tree = mmcs.commit(mats)
+        inter = []
+        for m in mats:
+            inter += [m, oracle.rng_fill_field(host, m.shape[0] * 4).reshape(m.shape[0], 4)]
+        exp_root, otree = oracle.mmcs_commit(inter, kind=kind)
+        assert np.array_equal(root, exp_root)
+        for index in (0, 5, mats[0].shape[0] - 1):
+            vals, (salts, path) = mmcs.open_batch(index, tree)
+            orows, opath = otree.open_batch(index)
+            got = np.concatenate([np.concatenate([v, s]) for v, s in zip(vals, salts)])
+            assert np.array_equal(got, orows) and np.array_equal(path, opath)
+            dims = [(m.shape[0], m.shape[1]) for m in inter]
+            assert oracle.mmcs_verify_batch(root, dims, index, got, path, kind=kind)
+        tree.free()

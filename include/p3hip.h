@@ -85,6 +85,11 @@ int p3hip_coset_dft_batch_bb31(const uint32_t *in, uint32_t *out, size_t height,
  * bit_reversed_out != 0).  out has (height << added_bits) rows. */
 int p3hip_coset_lde_batch_bb31(const uint32_t *in, uint32_t *out, size_t height, size_t width,
                                unsigned added_bits, uint32_t shift_monty, int bit_reversed_out);
+/* The reference logs one line per DFT call (backend_vulkan.rs:1385-1423: upload / stages / readback / total, plus the GPU
+ * timestamps).  The host-pointer entry points above keep the same line — "hip dft: op=.. h=.. w=.. stages=..
+ * upload=..ms stages=..ms readback=..ms total=..ms gpu(stage=..ms copy_back=..ms total=..ms)" — for the calling thread's
+ * last call (NULL before the first); with P3HIP_LOG_TIMING=1 it is also written to stderr like the reference's. */
+const char *p3hip_last_timing_line(void);
 /* device-resident forms — the reference's "kernel-only" view (backend_vulkan.rs:1428-1693) */
 int p3hip_dft_batch_bb31_dev(const uint32_t *d_in, uint32_t *d_out, size_t height, size_t width, void *stream);
 int p3hip_idft_batch_bb31_dev(const uint32_t *d_in, uint32_t *d_out, size_t height, size_t width, void *stream);
@@ -105,6 +110,14 @@ int p3hip_fib_trace_dev(uint64_t a, uint64_t b, size_t n, uint32_t *d_out, void 
 /* n independent width-16 states, in place. */
 int p3hip_poseidon2_permute_dev(uint32_t *d_states, size_t n, void *stream);
 int p3hip_poseidon2_permute(uint32_t *states, size_t n);
+/* The permutation exists in two arithmetic forms that must agree word for word: int32 Montgomery (variant 0) and exact
+ * integer arithmetic in fp64 (variant 1: what the large tree layers run).  Diagnostics / tests:
+ *   _variant_dev  the chosen form on n states in place;
+ *   _f64_probe    the fp64 form on integer-valued DOUBLES (16 per state) of any magnitude its contract allows, canonical
+ *                 Montgomery words out — mode 0: whole permutation (|v| <= 2^33), 1: the 13 internal rounds (|v| <= 2^37),
+ *                 2: the modular reduction alone. */
+int p3hip_poseidon2_permute_variant_dev(uint32_t *d_states, size_t n, int variant, void *stream);
+int p3hip_poseidon2_f64_probe_dev(const double *d_in, uint32_t *d_out, size_t n, int mode, void *stream);
 
 /* ---- Mmcs<BabyBear>: MerkleTreeMmcs<Poseidon2 sponge 16/8/8, TruncatedPermutation 2/8/16, digest 8>
  *      (the Poseidon2 analogue of the Keccak MMCS wired at native/src/fib_air.rs:31-51) ------------ */

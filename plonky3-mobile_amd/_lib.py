@@ -19,6 +19,7 @@ _SIGS = {
     "p3hip_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "p3hip_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "p3hip_sync": (C.c_int, [C.c_void_p]),
+    "p3hip_last_timing_line": (C.c_char_p, []),
     "p3hip_release_thread_context": (None, []),
     "p3hip_dft_batch_bb31": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
     "p3hip_idft_batch_bb31": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
@@ -35,6 +36,8 @@ _SIGS = {
     "p3hip_fib_trace_dev": (C.c_int, [C.c_uint64, C.c_uint64, C.c_size_t, C.c_void_p, C.c_void_p]),
     "p3hip_poseidon2_permute_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "p3hip_poseidon2_permute": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "p3hip_poseidon2_permute_variant_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "p3hip_poseidon2_f64_probe_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "p3hip_mmcs_commit_dev": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
                                         C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
     "p3hip_mmcs_commit_async_dev": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),

@@ -4,6 +4,7 @@
 #include "../../include/p3hip.h"
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -135,6 +136,17 @@ static int dft_dev(DftOp op, const uint32_t* d_in, uint32_t* d_out, size_t h, si
     });
 }
 
+// Per-call timing line of the reference's backend (backend_vulkan.rs:1385-1423, log_vulkan_timing :23-39):
+//   "vulkan dft: h=.. w=.. stages=.. upload=..ms stages=..ms readback=..ms total=..ms gpu(stage=.. copy_back=.. total=..)"
+// Here: "hip dft: ..." with the gpu(...) part from HIP events on the stream.  Written to stderr when
+// P3HIP_LOG_TIMING=1 (the reference always logs; a library should not) and always kept as the thread's last line
+// (p3hip_last_timing_line), so a host can surface it like the reference's logcat line.
+static thread_local std::string g_last_timing;
+static bool log_timing_enabled() {
+    static const bool on = [] { const char* e = getenv("P3HIP_LOG_TIMING"); return e && atoi(e) != 0; }();
+    return on;
+}
+
 // host-pointer path: H2D, kernels, D2H, sync (the reference's e2e shape, backend_vulkan.rs:1107-1394)
 static int dft_host(DftOp op, const uint32_t* in, uint32_t* out, size_t h, size_t w, unsigned added_bits,
                     uint32_t shift, int br_out) {
@@ -145,6 +157,9 @@ static int dft_host(DftOp op, const uint32_t* in, uint32_t* out, size_t h, size_
         Context* cx;
         int rc = get_context(&cx);
         if (rc) return rc;
+        using clk = std::chrono::steady_clock;
+        auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+        const auto t_total = clk::now();
         size_t in_bytes = h * w * 4;
         size_t out_rows = op == OP_COSET_LDE ? (h << added_bits) : h;
         size_t out_bytes = out_rows * w * 4;
@@ -153,16 +168,42 @@ static int dft_host(DftOp op, const uint32_t* in, uint32_t* out, size_t h, size_
         if (rc) return rc;
         rc = cx->ws(stream, 3).reserve(out_bytes);
         if (rc) return rc;
-        P3_HIP(hipMemcpyAsync(cx->ws(stream, 2).ptr, in, in_bytes, hipMemcpyHostToDevice, stream));
+        hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+        for (auto& e : ev) P3_HIP(hipEventCreate(&e));
+        auto drop_events = [&] { for (auto& e : ev) if (e) (void)hipEventDestroy(e); };
+        const auto t_upload = clk::now();
+        if (hipMemcpyAsync(cx->ws(stream, 2).ptr, in, in_bytes, hipMemcpyHostToDevice, stream) != hipSuccess) { drop_events(); return fail(ERR_HIP, "upload failed"); }
+        (void)hipEventRecord(ev[0], stream);
+        const double upload_ms = ms_since(t_upload);
+        const auto t_stages = clk::now();
         rc = dft_dev(op, cx->ws(stream, 2).as<uint32_t>(), cx->ws(stream, 3).as<uint32_t>(), h, w, added_bits, shift, br_out, stream);
-        if (rc) return rc;
-        P3_HIP(hipMemcpyAsync(out, cx->ws(stream, 3).ptr, out_bytes, hipMemcpyDeviceToHost, stream));
-        P3_HIP(hipStreamSynchronize(stream));
+        if (rc) { drop_events(); return rc; }
+        (void)hipEventRecord(ev[1], stream);
+        const double stages_ms = ms_since(t_stages);
+        const auto t_read = clk::now();
+        if (hipMemcpyAsync(out, cx->ws(stream, 3).ptr, out_bytes, hipMemcpyDeviceToHost, stream) != hipSuccess) { drop_events(); return fail(ERR_HIP, "readback failed"); }
+        (void)hipEventRecord(ev[2], stream);
+        if (hipStreamSynchronize(stream) != hipSuccess) { drop_events(); return fail(ERR_HIP, "synchronise failed"); }
+        const double readback_ms = ms_since(t_read), total_ms = ms_since(t_total);
+        float g_stage = 0, g_copy = 0, g_total = 0;
+        (void)hipEventElapsedTime(&g_stage, ev[0], ev[1]);
+        (void)hipEventElapsedTime(&g_copy, ev[1], ev[2]);
+        (void)hipEventElapsedTime(&g_total, ev[0], ev[2]);
+        drop_events();
+        char line[320];
+        snprintf(line, sizeof line,
+                 "hip dft: op=%s h=%zu w=%zu stages=%u upload=%.3fms stages=%.3fms readback=%.3fms total=%.3fms gpu(stage=%.3fms copy_back=%.3fms total=%.3fms)",
+                 op == OP_DFT ? "dft" : op == OP_IDFT ? "idft" : op == OP_COSET_DFT ? "coset_dft" : "coset_lde", h, w,
+                 log2u(out_rows), upload_ms, stages_ms, readback_ms, total_ms, g_stage, g_copy, g_total);
+        g_last_timing = line;
+        if (log_timing_enabled()) fprintf(stderr, "%s\n", line);
         return OK;
     });
 }
 
 extern "C" {
+
+const char* p3hip_last_timing_line(void) { return g_last_timing.empty() ? nullptr : g_last_timing.c_str(); }
 
 int p3hip_dft_batch_bb31(const uint32_t* in, uint32_t* out, size_t h, size_t w) {
     return dft_host(OP_DFT, in, out, h, w, 0, bb::ONE, 0);
@@ -238,10 +279,34 @@ int p3hip_poseidon2_permute(uint32_t* states, size_t n) {
     });
 }
 
+// test / diagnostics entries of the two arithmetic forms of the permutation
+int p3hip_poseidon2_permute_variant_dev(uint32_t* d_states, size_t n, int variant, void* stream) {
+    return guarded([&]() -> int {
+        if (n && !d_states) return fail(ERR_BAD_ARG, "null state pointer");
+        if (variant != 0 && variant != 1) return fail(ERR_BAD_ARG, "poseidon2 variant: 0 = int32, 1 = fp64");
+        Context* cx;
+        int rc = get_context(&cx);
+        if (rc) return rc;
+        return poseidon2_permute_states_variant((hipStream_t)stream, d_states, n, variant);
+    });
+}
+int p3hip_poseidon2_f64_probe_dev(const double* d_in, uint32_t* d_out, size_t n, int mode, void* stream) {
+    return guarded([&]() -> int {
+        if (n && (!d_in || !d_out)) return fail(ERR_BAD_ARG, "null pointer");
+        if (mode < 0 || mode > 2) return fail(ERR_BAD_ARG, "probe mode: 0 = permutation, 1 = internal rounds, 2 = reduce");
+        Context* cx;
+        int rc = get_context(&cx);
+        if (rc) return rc;
+        return poseidon2_f64_probe((hipStream_t)stream, d_in, d_out, n, mode);
+    });
+}
+
 // ---- Mmcs ---------------------------------------------------------------------------------------
+}  // extern "C"
 struct p3hip_tree {
     Tree* t;
 };
+extern "C" {
 
 static int commit_async_kind(int kind, const uint32_t* const* d_mats, const size_t* heights, const size_t* widths,
                              size_t n_mats, p3hip_tree_t** tree_out, void* stream) {

@@ -31,6 +31,8 @@ inline size_t mmcs_layer_words(uint64_t max_height) { return (size_t)(2 * max_he
 int mmcs_root(hipStream_t stream, const Tree& t, uint32_t root_out[8]);
 int mmcs_open(hipStream_t stream, const Tree& t, uint64_t index, uint32_t* rows_out, uint32_t* path_out);
 int poseidon2_permute_states(hipStream_t stream, uint32_t* d_states, uint64_t n);
+int poseidon2_f64_probe(hipStream_t stream, const double* d_in, uint32_t* d_out, uint64_t n, int mode);
+int poseidon2_permute_states_variant(hipStream_t stream, uint32_t* d_states, uint64_t n, int variant);
 int keccak_f_states(hipStream_t stream, uint64_t* d_states, uint64_t n);
 
 }  // namespace p3

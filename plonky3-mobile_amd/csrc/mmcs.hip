@@ -275,6 +275,40 @@ __global__ void poseidon2_permute_f64_kernel(uint32_t* states, uint64_t n) {
         q[k] = make_uint4(p2f::store_elem(s[4 * k]), p2f::store_elem(s[4 * k + 1]), p2f::store_elem(s[4 * k + 2]), p2f::store_elem(s[4 * k + 3]));
 }
 
+// Test probe of the fp64 arithmetic: integer-valued doubles in (any magnitude the contract of the probed part allows),
+// canonical Montgomery words out.  mode 0: the whole permutation (|v| <= 2^33); mode 1: the 13 internal rounds only
+// (|v| <= 2^37 — the magnitudes the external layer can hand them, which no u32 input of the permutation reaches
+// deterministically); mode 2: reduce() alone, lane by lane (rounding ties of the quotient estimate).
+__global__ void poseidon2_f64_probe_kernel(const double* in, uint32_t* out, uint64_t n, int mode) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) s[k] = in[i * 16 + k];
+    if (mode == 0) p2f::permute(s);
+    else if (mode == 1) p2f::internal_rounds(s);
+    else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) s[k] = p2f::reduce(s[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) out[i * 16 + k] = p2f::store_elem(s[k]);
+}
+int poseidon2_f64_probe(hipStream_t stream, const double* d_in, uint32_t* d_out, uint64_t n, int mode) {
+    if (!n) return OK;
+    hipLaunchKernelGGL(poseidon2_f64_probe_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_in, d_out, n, mode);
+    P3_HIP(hipGetLastError());
+    return OK;
+}
+// variant: 0 = int32 Montgomery form, 1 = fp64 form (the two must agree word for word)
+int poseidon2_permute_states_variant(hipStream_t stream, uint32_t* d_states, uint64_t n, int variant) {
+    if (!n) return OK;
+    if (variant == 1) hipLaunchKernelGGL(poseidon2_permute_f64_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_states, n);
+    else hipLaunchKernelGGL(poseidon2_permute_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_states, n);
+    P3_HIP(hipGetLastError());
+    return OK;
+}
+
 int poseidon2_permute_states(hipStream_t stream, uint32_t* d_states, uint64_t n) {
     static int use_f64 = [] { const char* e = getenv("P3HIP_P2_F64"); return e ? atoi(e) : 1; }();
     static int use_x2 = [] { const char* e = getenv("P3HIP_P2_X2"); return e ? atoi(e) : 0; }();

@@ -91,18 +91,11 @@ __device__ __forceinline__ void external_linear(double (&s)[16]) {
     for (int i = 0; i < 16; i++) s[i] += t[i & 3];
 }
 
-// |s_i| <= 2^33 on entry (canonical inputs or compress inputs < P); every intermediate stays below 2^50.
-__device__ __forceinline__ void permute(double (&s)[16]) {
-    external_linear(s);  // <= 35 * 2^33 < 2^39
-    _Pragma("clang loop unroll(disable)")
-    for (int r = 0; r < 4; r++) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) s[i] = sbox7(s[i] + d_c.ext[r][i]);  // |.| < 1.1 P
-        external_linear(s);                                                // < 39 P < 2^37
-    }
-    // V = [-2, 1, 2, 1/2, 3, 4, -1/2, -3, -4, 2^-8, 1/4, 1/8, 2^-27, -2^-8, -1/16, -2^-27]; 2^-27 = -15 (mod P)
-    // because P - 1 = 15 * 2^27.  The integer-multiplier lanes grow up to 15x per round: fold them back after
-    // every fourth round (15^4 * 2^31 < 2^47); the fractional lanes stay below 3P by themselves.
+// The 13 internal rounds.  Entry: integers |s_i| <= 2^37 (what the fourth external round leaves: 35 (P/2 + 1) < 2^36).
+// V = [-2, 1, 2, 1/2, 3, 4, -1/2, -3, -4, 2^-8, 1/4, 1/8, 2^-27, -2^-8, -1/16, -2^-27]; 2^-27 = -15 (mod P)
+// because P - 1 = 15 * 2^27.  The integer-multiplier lanes grow up to 15x per round: fold them back after
+// every fourth round (15^4 * 2^37 < 2^53: still exact integers); the fractional lanes stay below their entry bound.
+__device__ __forceinline__ void internal_rounds(double (&s)[16]) {
     const double k3 = d_c.k3, k15 = d_c.k15, i4 = d_c.i4, i8 = d_c.i8, i16 = d_c.i16, i256 = d_c.i256;
     auto internal_round = [&](int r) {
         s[0] = sbox7(s[0] + d_c.in[r]);
@@ -138,6 +131,18 @@ __device__ __forceinline__ void permute(double (&s)[16]) {
     }
     internal_round(12);
     fold_integer_lanes();
+}
+
+// |s_i| <= 2^33 on entry (canonical inputs or compress inputs < P); every intermediate stays below 2^53.
+__device__ __forceinline__ void permute(double (&s)[16]) {
+    external_linear(s);  // <= 35 * 2^33 < 2^39
+    _Pragma("clang loop unroll(disable)")
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = sbox7(s[i] + d_c.ext[r][i]);  // |.| <= P/2 + 1
+        external_linear(s);                                                // <= 35 (P/2 + 1) < 2^36
+    }
+    internal_rounds(s);
     _Pragma("clang loop unroll(disable)")
     for (int r = 4; r < 8; r++) {
 #pragma unroll

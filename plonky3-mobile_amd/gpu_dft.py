@@ -49,6 +49,12 @@ def take_last_error():
     return _lib.take_last_error()
 
 
+def last_timing_line():
+    """The reference's per-call log line (backend_vulkan.rs:1385-1423) for this thread's last host-pointer DFT call."""
+    m = _lib.lib().p3hip_last_timing_line()
+    return m.decode() if m else None
+
+
 def is_available():
     """lib.rs:167-179 isVulkanAvailable: (ok, message)."""
     buf = C.create_string_buffer(256)

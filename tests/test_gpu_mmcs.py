@@ -106,3 +106,88 @@ def test_mmcs_randomized_dims(p3, oracle):
         orows, opath = otree.open_batch(idx)
         assert np.array_equal(np.concatenate(rows), orows) and np.array_equal(path, opath), (it, dims, idx)
         tree.free()
+
+
+def _probe(p3, states_f64, mode):
+    """p3hip_poseidon2_f64_probe_dev: integer-valued doubles in, canonical values out (numpy uint32, canonical form)."""
+    import ctypes as C
+    import torch
+    from plonky3_mobile_amd import _lib
+    d = torch.from_numpy(np.ascontiguousarray(states_f64, dtype=np.float64)).cuda()
+    out = torch.empty(d.shape, dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().p3hip_poseidon2_f64_probe_dev(C.c_void_p(d.data_ptr()), C.c_void_p(out.data_ptr()), d.shape[0], mode,
+                                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    return out.cpu().numpy().view(np.uint32)
+
+
+def test_fp64_reduce_at_rounding_ties(p3, oracle):
+    """reduce(x) = x - rint(x / P) P for integers x straddling the half-way points ((2k+1) P +- 1) / 2 (where the
+    quotient estimate's fraction is closest to .5), at every magnitude up to 2^52, and at +-(2^52 .. 2^53): the result
+    must be congruent to x, whatever way the tie falls."""
+    xs = []
+    for k in list(range(0, 40)) + [2 ** e for e in range(6, 22)] + [2 ** 21 + 12345, 2 ** 21 - 1]:
+        for d in (-3, -1, 1, 3):
+            x = ((2 * k + 1) * P + d) // 2
+            if x < 2 ** 52:
+                xs += [x, -x]
+    xs += [2 ** 52 - 1, -(2 ** 52 - 1), 2 ** 52 + 2, 15 ** 4 * 35 * (P // 2 + 1), -(15 ** 4 * 35 * (P // 2 + 1))]
+    xs += [0, 1, -1, P, -P, P - 1, P // 2, P // 2 + 1, -(P // 2), -(P // 2 + 1)]
+    while len(xs) % 16:
+        xs.append(0)
+    arr = np.array(xs, dtype=np.float64).reshape(-1, 16)
+    assert all(int(v) == x for v, x in zip(arr.reshape(-1), xs))  # all exactly representable
+    got = oracle.from_monty(_probe(p3, arr, 2)).reshape(-1)
+    assert got.tolist() == [x % P for x in xs]
+
+
+def test_fp64_internal_rounds_at_the_largest_magnitudes(p3, oracle):
+    """The 13 internal rounds of the fp64 form on states as large as the external layer can hand them (|v| up to
+    35 (P/2 + 1) < 2^36, a bound no u32 input reaches deterministically), with the sign patterns that maximise the
+    integer-multiplier lanes 1, 2, 4, 5, 7, 8, 12, 15 (they grow by up to 15x per round between two folds) and the
+    lane sum, against exact big-integer arithmetic."""
+    import pyref
+    M = 35 * (P // 2 + 1)
+    diag_sign = [-1, 1, 1, 1, 1, 1, -1, -1, -1, 1, 1, 1, -1, -1, -1, 1]  # sign of V[i]: aligned signs add up
+    rng = np.random.default_rng(5)
+    states = [[M] * 16, [-M] * 16, [M * s for s in diag_sign], [-M * s for s in diag_sign],
+              [M if i in (1, 2, 4, 5, 7, 8, 12, 15) else 0 for i in range(16)],
+              [(M if i % 2 else -M) for i in range(16)], [M - i for i in range(16)], [-(M - 7 * i) for i in range(16)]]
+    for _ in range(200):
+        mag = rng.integers(M - 2 ** 20, M + 1, size=16)
+        states.append([int(m) * int(s) for m, s in zip(mag, rng.choice([-1, 1], size=16))])
+    for _ in range(200):
+        states.append([int(v) for v in rng.integers(-M, M + 1, size=16)])
+    arr = np.array(states, dtype=np.float64)
+    got = oracle.from_monty(_probe(p3, arr, 1))
+    _, it, _ = pyref.DEFAULT_RC
+    for row, st in zip(got, states):
+        s = [v % P for v in st]
+        for r in range(13):
+            s[0] = pow((s[0] + it[r]) % P, 7, P)
+            s = pyref._int(s)
+        assert row.tolist() == s
+
+
+def test_fp64_and_int32_forms_agree_on_a_million_states(p3, oracle):
+    """The two arithmetic forms of the permutation (variant 0: int32 Montgomery, variant 1: exact integers in fp64) word
+    for word on 2^20 random states plus structured extremes; a sample against the oracle."""
+    import ctypes as C
+    import torch
+    from plonky3_mobile_amd import _lib
+    rng = np.random.default_rng(21)
+    st = _rand(rng, 1 << 20, 16)
+    st[0] = 0; st[1] = P - 1; st[2] = P // 2; st[3] = P // 2 + 1
+    st[4] = [(P - 1) if i in (1, 2, 4, 5, 7, 8, 12, 15) else 0 for i in range(16)]
+    st[5] = [(P - 1) if i % 2 else 1 for i in range(16)]
+    a, b = p3.dev_u32(st), p3.dev_u32(st)
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(_lib.lib().p3hip_poseidon2_permute_variant_dev(C.c_void_p(a.data_ptr()), st.shape[0], 0, sp))
+    _lib.check(_lib.lib().p3hip_poseidon2_permute_variant_dev(C.c_void_p(b.data_ptr()), st.shape[0], 1, sp))
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    got = p3.host_u32(b[:64])
+    assert np.array_equal(got, np.stack([oracle.poseidon2_permute(s) for s in st[:64]]))
+    # the same permutation through the probe on canonical doubles (mode 0)
+    canon = oracle.from_monty(st[:256]).astype(np.float64)
+    assert np.array_equal(_probe(p3, canon, 0), p3.host_u32(b[:256]))

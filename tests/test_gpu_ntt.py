@@ -296,3 +296,18 @@ def test_release_thread_context_and_reuse(dft, oracle, p3):
     _lib.lib().p3hip_release_thread_context()
     assert np.array_equal(dft.dft_batch(x), exp)
     assert np.array_equal(p3.host_u32(dft.dft_batch(p3.dev_u32(x))), exp)
+
+
+def test_per_call_timing_line(dft, oracle, p3):
+    """backend_vulkan.rs:1385-1423: one line per DFT call with upload / stages / readback / total and the GPU timestamps."""
+    import re
+    x = oracle.benchmark_input(4096, 8)
+    dft.dft_batch(x)
+    line = p3.last_timing_line()
+    m = re.match(r"hip dft: op=dft h=4096 w=8 stages=12 upload=([0-9.]+)ms stages=([0-9.]+)ms readback=([0-9.]+)ms total=([0-9.]+)ms "
+                 r"gpu\(stage=([0-9.]+)ms copy_back=([0-9.]+)ms total=([0-9.]+)ms\)$", line)
+    assert m, line
+    up, st, rb, tot, gs, gc, gt = map(float, m.groups())
+    assert tot >= rb and gt >= gs and gs > 0
+    dft.coset_lde_batch(x, 1, p3.GENERATOR_MONTY)
+    assert p3.last_timing_line().startswith("hip dft: op=coset_lde h=4096 w=8 stages=13 ")

@@ -815,7 +815,7 @@ int lde_fused(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* ds
 
 
 template <int B, int LQ, int VW, int K>
-int launch_narrow_t(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t blocks) {
+int launch_narrow_t(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t blocks, uint32_t grid_y = 1) {
     // padded tile (17 rows per 16 points; the middle kernel alternates two below 1024 threads) + stage-table prefixes
     constexpr size_t tile_bytes = ((size_t)4 * VW * narrow::lds_rows(B)) << LQ;
     // the middle kernel of 512-thread pair tiles runs column-sequentially (one pair tile, two workgroups per CU)
@@ -831,7 +831,7 @@ int launch_narrow_t(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32
         int rc = cx.ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(1u << (B - 4 + LQ)), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(blocks, K == 2 ? grid_y : 1u), dim3(1u << (B - 4 + LQ)), lds, stream, a);
     P3_HIP(hipGetLastError());
     return OK;
 }
@@ -839,19 +839,19 @@ int launch_narrow_t(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32
 // Tile rows are 32 bytes (LQ = 2 for pairs, 3 for single words), 16 bytes for 12-stage digits (64 KB tiles, <= 1024 threads).
 constexpr int narrow_lq(int b, int vw) { return (b == 12 ? 1 : 2) + (vw == 1 ? 1 : 0); }
 template <int K, int VW>
-int launch_narrow_v(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t b, uint32_t blocks) {
+int launch_narrow_v(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t b, uint32_t blocks, uint32_t gy) {
     switch (b) {
-        case 8: return launch_narrow_t<8, narrow_lq(8, VW), VW, K>(cx, stream, a, blocks);
-        case 9: return launch_narrow_t<9, narrow_lq(9, VW), VW, K>(cx, stream, a, blocks);
-        case 10: return launch_narrow_t<10, narrow_lq(10, VW), VW, K>(cx, stream, a, blocks);
-        case 11: return launch_narrow_t<11, narrow_lq(11, VW), VW, K>(cx, stream, a, blocks);
-        case 12: return launch_narrow_t<12, narrow_lq(12, VW), VW, K>(cx, stream, a, blocks);
+        case 8: return launch_narrow_t<8, narrow_lq(8, VW), VW, K>(cx, stream, a, blocks, gy);
+        case 9: return launch_narrow_t<9, narrow_lq(9, VW), VW, K>(cx, stream, a, blocks, gy);
+        case 10: return launch_narrow_t<10, narrow_lq(10, VW), VW, K>(cx, stream, a, blocks, gy);
+        case 11: return launch_narrow_t<11, narrow_lq(11, VW), VW, K>(cx, stream, a, blocks, gy);
+        case 12: return launch_narrow_t<12, narrow_lq(12, VW), VW, K>(cx, stream, a, blocks, gy);
         default: return fail(ERR_INTERNAL, "lde_narrow: digit out of range");
     }
 }
 template <int K>
-int launch_narrow(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t b, uint32_t blocks, int vw) {
-    return vw == 1 ? launch_narrow_v<K, 1>(cx, stream, a, b, blocks) : launch_narrow_v<K, 2>(cx, stream, a, b, blocks);
+int launch_narrow(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t b, uint32_t blocks, int vw, uint32_t gy = 1) {
+    return vw == 1 ? launch_narrow_v<K, 1>(cx, stream, a, b, blocks, gy) : launch_narrow_v<K, 2>(cx, stream, a, b, blocks, gy);
 }
 
 // Narrow-matrix coset LDE in three launches (ntt_narrow.cuh).  Returns 1 when the shape is not covered.
@@ -916,7 +916,17 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
         base = bb::mul(base, g);
     }
     tiles = geometry(1, n2, 1ull << n1);
-    if ((rc = launch_narrow<2>(cx, stream, a, n2, tiles, vw[1]))) return rc;
+    // Grids that leave CUs idle (fewer workgroups than CUs): split the cosets over workgroups.  Every workgroup repeats
+    // the inverse digit (more arithmetic), but idle CUs take the extra workgroups: 2^16..2^18 rows gain 5-25 %
+    // (gpurun_out sweep, profiles/r02_lde_sweep_cosplit.txt); from one workgroup per CU on the kernel is bound by its
+    // arithmetic and a split only adds to it (2^20 x 2: 52.4 -> 55.7 us), so the split stops at 256 workgroups.
+    // P3HIP_NTT_NARROW_COSSPLIT=0 disables, =n forces 2^n-way.
+    static int cos_split = [] { const char* e = getenv("P3HIP_NTT_NARROW_COSSPLIT"); return e ? atoi(e) : -1; }();
+    uint32_t split_log = 0;
+    if (cos_split < 0) { while (split_log < added && ((uint64_t)tiles << (split_log + 1)) <= 256) split_log++; }
+    else split_log = std::min<uint32_t>((uint32_t)cos_split, added);
+    a.cos_per_block = (1u << added) >> split_log;
+    if ((rc = launch_narrow<2>(cx, stream, a, n2, tiles, vw[1], 1u << split_log))) return rc;
     // K3
     a.src = dst; a.dst = dst;
     a.stage_tw = cx.tile_tw[0];

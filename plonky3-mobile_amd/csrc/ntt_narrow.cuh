@@ -70,6 +70,8 @@ struct NarrowArgs {
     uint32_t sc_phi[8];           // (shift g^j)^(N1 * 2^(n2-4))
     uint32_t xcd_remap;           // 1: tile count is a multiple of 32, spread groups of 4 adjacent tiles per XCD
     uint32_t mid_handover;        // blocked: the middle kernel re-sorts its results through LDS to store whole lines
+    uint32_t cos_per_block;       // K2: cosets one workgroup transforms (grid.y = 2^added / cos_per_block); splitting the
+                                  // cosets over workgroups repeats the inverse digit but doubles a thin grid's waves
     uint32_t blocked;             // W = 2: the two intermediates are stored in 128-byte blocks of
                                   // 4 x 4 (row of one digit, row of the other) pairs, so that the kernel that reads
                                   // them strided touches whole cache lines instead of 32-byte segments
@@ -350,13 +352,13 @@ narrow_mid_kernel(NarrowArgs a) {
     const uint32_t c0 = two_level(a.twf_lo, a.twf_hi, a.twf_T, (uint64_t)k1 * rev_bits(t, B - 4));
     const uint32_t phi0 = two_level(a.twf_lo, a.twf_hi, a.twf_T, (uint64_t)k1 << (B - 4));
     const uint64_t kbase = (uint64_t)k1 + ((uint64_t)t << a.n1);
-    uint32_t sc_next = two_level(a.sc_lo[0], a.sc_hi[0], a.sc_T, kbase);
+    const uint32_t cos0 = blockIdx.y * a.cos_per_block, ncos = cos0 + a.cos_per_block;  // this workgroup's cosets
+    uint32_t sc_next = two_level(a.sc_lo[cos0], a.sc_hi[cos0], a.sc_T, kbase);
     to_natural<B, LQ>(tile, c, t, q);  // c[j] = coefficient k = k1 + N1 * k2, k2 = pt_of<B-4>(t, j) = (j << (B-4)) | t
-    const uint32_t ncos = 1u << a.added;
     if constexpr (SEQ) {
         __syncthreads();  // the 32-bit tiles below alias the pair tile: its last reads (to_natural) are done
         Tiles<uint32_t, true> t32{smem, smem + (lds_rows(B) << LQ)};
-        for (uint32_t jc = 0; jc < ncos; jc++) {
+        for (uint32_t jc = cos0; jc < ncos; jc++) {
             const uint32_t sc = sc_next;
             if (jc + 1 < ncos) sc_next = two_level(a.sc_lo[jc + 1], a.sc_hi[jc + 1], a.sc_T, kbase);
             // per column: round-1 twiddles and the scale ladder are rebuilt (15 loads + 18 products) rather than kept
@@ -392,7 +394,7 @@ narrow_mid_kernel(NarrowArgs a) {
     } else {
         uint32_t pw2[16];
         if constexpr (!LEAN) power_ladder<16>(c0, phi0, pw2);
-        for (uint32_t jc = 0; jc < ncos; jc++) {
+        for (uint32_t jc = cos0; jc < ncos; jc++) {
             const uint32_t sc = sc_next;
             if (jc + 1 < ncos) sc_next = two_level(a.sc_lo[jc + 1], a.sc_hi[jc + 1], a.sc_T, kbase);
             uint32_t w1[15];  // in flight while the scale ladder runs

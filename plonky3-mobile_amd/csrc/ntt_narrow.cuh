@@ -43,6 +43,12 @@
 #ifndef NARROW_SKIP
 #define NARROW_SKIP 0  // experiment builds only: 1 = no butterflies / ladders (the load, LDS and store skeleton alone)
 #endif
+#ifndef NARROW_TW_SHUFFLE
+#define NARROW_TW_SHUFFLE 0  // A/B build for north_star's "wavefront-shuffle twiddle broadcast": 1 = the stage twiddles of the
+                             // rounds after the first (stages below 6: at most 32 distinct values) are held one per lane
+                             // and fetched with a wave shuffle (ds_bpermute) instead of the LDS broadcast read.  Measured
+                             // on narrow_fwd2_kernel<10,..>: profiles/r02_twiddle_shuffle_vs_lds.txt — default stays 0.
+#endif
 #ifndef NARROW_MID_SEQ_WAVES
 #define NARROW_MID_SEQ_WAVES 4
 #endif
@@ -128,9 +134,17 @@ __device__ __forceinline__ void stage_block(V (&v)[16], const uint32_t* __restri
         const int d = u - A;
         uint32_t w[8];
         if (u > 0) {
+            if (NARROW_TW_SHUFFLE && u <= 6) {
+                // one table entry per lane (2^u <= 64 of them), handed to the lanes that need it by a wave shuffle
+                const uint32_t mine = tw[(1u << u) - 1u + (threadIdx.x & ((1u << u) - 1u))];
 #pragma unroll
-            for (int jl = 0; jl < 8; jl++)
-                if (jl < (1 << d)) w[jl] = tw[(1u << u) - 1u + (tlo | ((uint32_t)jl << A))];
+                for (int jl = 0; jl < 8; jl++)
+                    if (jl < (1 << d)) w[jl] = (uint32_t)__shfl((int)mine, (int)(tlo | ((uint32_t)jl << A)), 64);
+            } else {
+#pragma unroll
+                for (int jl = 0; jl < 8; jl++)
+                    if (jl < (1 << d)) w[jl] = tw[(1u << u) - 1u + (tlo | ((uint32_t)jl << A))];
+            }
         }
 #pragma unroll
         for (int j0 = 0; j0 < 16; j0++) {

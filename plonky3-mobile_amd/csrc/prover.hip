@@ -400,7 +400,14 @@ __global__ void __launch_bounds__(TS_OPEN_THREADS) ts_open_kernel(TsArgs a, cons
     {
         const uint32_t col = threadIdx.x & 31u, part = threadIdx.x >> 5;
         uint32_t v = 0;
-        for (uint32_t b = part; b < n_blocks; b += TS_OPEN_THREADS / 32) v = bb::add(v, partials[b * 32 + col]);
+        constexpr uint32_t STEP = TS_OPEN_THREADS / 32;
+        uint32_t b = part;
+        for (; b + 3 * STEP < n_blocks; b += 4 * STEP) {  // four independent loads in flight per lane
+            const uint32_t p0 = partials[b * 32 + col], p1 = partials[(b + STEP) * 32 + col],
+                           p2 = partials[(b + 2 * STEP) * 32 + col], p3 = partials[(b + 3 * STEP) * 32 + col];
+            v = bb::add(bb::add(v, bb::add(p0, p1)), bb::add(p2, p3));
+        }
+        for (; b < n_blocks; b += STEP) v = bb::add(v, partials[b * 32 + col]);
         red[part][col] = v;
     }
     __syncthreads();
@@ -605,7 +612,9 @@ int FibProver::init(uint32_t log_n, const FriParams& fp, hipStream_t stream, boo
     for (uint32_t r = 0; r < s.n_rounds; r++) { s.fri_layer_off.push_back(layer_words); layer_words += mmcs_layer_words(big >> (r + 1)); }
     if ((rc = s.alloc(&s.fri_vec, vec_words))) return rc;
     if ((rc = s.alloc(&s.fri_layers, layer_words + 8))) return rc;
-    s.bary_blocks = (uint32_t)std::min<size_t>(1024, (n + BARY_BLOCK - 1) / BARY_BLOCK);
+    // 256 workgroups: each lane then folds 16 rows at 2^20 before the 32 wave reductions (which cost as much as ~3 rows),
+    // and the transcript kernel that finishes the sums reads 256 x 32 partial words instead of 1024 x 32
+    s.bary_blocks = (uint32_t)std::min<size_t>(256, (n + BARY_BLOCK - 1) / BARY_BLOCK);
     if ((rc = s.alloc(&s.partials, (size_t)s.bary_blocks * 32))) return rc;
     const size_t fpl = (size_t)1 << fp.log_final_poly_len;
     if ((rc = s.alloc(&s.fp_ev, fpl * 4))) return rc;

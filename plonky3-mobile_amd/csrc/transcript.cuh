@@ -6,7 +6,8 @@
 //   HASH_KECCAK     SerializingChallenger32<BabyBear, HashChallenger<u8, Keccak256Hash, 32>> (native/src/fib_air.rs:53):
 //                   kept as a STREAMING sponge — the chaining digest and the observed bytes are absorbed as they arrive,
 //                   so at any time the state is "full blocks absorbed + a partial block", which is also exactly what
-//                   the proof-of-work search needs.  Lane 0 runs it; results are broadcast.
+//                   the proof-of-work search needs.  The bookkeeping is wave-uniform, the permutation lane-cooperative
+//                   (one state word per lane, shuffles for theta / pi / chi).
 // Same conventions as the host classes (p3-challenger 0.4.2 is absent: [UPSTREAM-RECALL], see challenger.h); the proofs
 // these produce are compared byte for byte with the host transcript of the CPU restatement in tests/.
 #pragma once
@@ -75,46 +76,86 @@ struct DevState {
     KeccakGrindArgs kgrind;
 };
 
-// ---- Keccak streaming sponge on the LDS copy; called by lane 0 only.  Not inlined: one copy of the permutation per
-// kernel, and the challenger object itself stays in registers.
-__device__ __noinline__ void k_absorb_block(KState* k) {
-    uint64_t a[25];
+// ---- Keccak streaming sponge on the LDS copy.  EVERY lane of the wave runs these functions with the same (uniform)
+// control flow: the scalar bookkeeping is read by all lanes and written by lane 0, and the permutation is
+// lane-cooperative — state lane i = x + 5y lives in wave lane i, theta / pi / chi move data with wave shuffles: about
+// 50 wave-instructions per round instead of ~260 for one lane holding all 25 words, i.e. a flush costs ~4 us of
+// latency instead of ~27.  Not inlined: one copy of the permutation per kernel.
+__device__ __forceinline__ void lds_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, uint32_t src) {
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, (int)src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), (int)src, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __noinline__ uint64_t keccak_f_coop(uint64_t a) {  // lanes >= 25 carry don't-care values
+    const uint32_t lane = threadIdx.x & 63u, l = lane < 25u ? lane : 0u, x = l % 5u, y = l / 5u;
+    const uint32_t col1 = x + 5u * ((y + 1u) % 5u), col2 = x + 5u * ((y + 2u) % 5u), col3 = x + 5u * ((y + 3u) % 5u),
+                   col4 = x + 5u * ((y + 4u) % 5u);
+    const uint32_t xm1 = (x + 4u) % 5u + 5u * y, xp1 = (x + 1u) % 5u + 5u * y, xp2 = (x + 2u) % 5u + 5u * y;
+    // pi: B[y' + 5 ((2x' + 3y') % 5)] = rot(A[x' + 5y']); the lane at (X, Y) therefore reads from x' = (X + 3Y) % 5, y' = X
+    const uint32_t pi_src = (x + 3u * y) % 5u + 5u * x;
+    constexpr uint8_t RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+    uint32_t rho = 0;
 #pragma unroll
-    for (int i = 0; i < 25; i++) a[i] = k->st[i];
-#pragma unroll
-    for (int i = 0; i < 17; i++) {
-        uint64_t w = 0;
-        for (int b = 0; b < 8; b++) w |= (uint64_t)k->blk[8 * i + b] << (8 * b);
-        a[i] ^= w;
+    for (uint32_t i = 0; i < 25; i++) rho = l == i ? RHO[i] : rho;
+    _Pragma("clang loop unroll(disable)")
+    for (int r = 0; r < 24; r++) {
+        const uint64_t c = a ^ shfl64(a, col1) ^ shfl64(a, col2) ^ shfl64(a, col3) ^ shfl64(a, col4);  // column parity
+        const uint64_t cp = shfl64(c, xp1);
+        a ^= shfl64(c, xm1) ^ ((cp << 1) | (cp >> 63));
+        const uint64_t rot = (a << rho) | (a >> ((64u - rho) & 63u));
+        const uint64_t bb = shfl64(rot, pi_src);
+        a = bb ^ (~shfl64(bb, xp1) & shfl64(bb, xp2));
+        if (lane == 0) a ^= kk::d_rc[r];
     }
-    kk::permute(a);
+    return a;
+}
+__device__ __noinline__ void k_absorb_block(KState* k) {
+    const uint32_t lane = threadIdx.x & 63u;
+    lds_wave_sync();
+    uint64_t a = lane < 25u ? k->st[lane] : 0ull;
+    if (lane < 17u) {
+        uint64_t w = 0;
 #pragma unroll
-    for (int i = 0; i < 25; i++) k->st[i] = a[i];
-    k->blen = 0;
+        for (int b = 0; b < 8; b++) w |= (uint64_t)k->blk[8 * lane + b] << (8 * b);
+        a ^= w;
+    }
+    a = keccak_f_coop(a);
+    if (lane < 25u) k->st[lane] = a;
+    if (lane == 0) k->blen = 0;
+    lds_wave_sync();
 }
 __device__ __forceinline__ void k_observe_byte(KState* k, uint8_t b) {
-    k->n_obuf = 0;
-    k->blk[k->blen++] = b;
-    if (k->blen == 136) k_absorb_block(k);
+    const uint32_t bl = k->blen;  // the same word for every lane
+    if ((threadIdx.x & 63u) == 0) { k->n_obuf = 0; k->blk[bl] = b; k->blen = bl + 1; }
+    lds_wave_sync();
+    if (bl + 1 == 136) k_absorb_block(k);
 }
 __device__ __noinline__ void k_flush(KState* k) {  // output = Keccak256(input); the digest also starts the next input
-    uint32_t n = k->blen;
-    for (uint32_t i = n; i < 136; i++) k->blk[i] = 0;
-    k->blk[n] ^= 0x01;
-    k->blk[135] ^= 0x80;
+    const uint32_t lane = threadIdx.x & 63u, n = k->blen;
+    for (uint32_t i = n + lane; i < 136; i += 64) k->blk[i] = 0;
+    lds_wave_sync();
+    if (lane == 0) { k->blk[n] ^= 0x01; k->blk[135] ^= 0x80; }
     k_absorb_block(k);
-    for (int i = 0; i < 32; i++) k->obuf[i] = (uint8_t)(k->st[i >> 3] >> (8 * (i & 7)));
-    for (int i = 0; i < 25; i++) k->st[i] = 0;
-    for (int i = 0; i < 32; i++) k->blk[i] = k->obuf[i];
-    k->blen = 32;
-    k->n_obuf = 32;
+    uint8_t byte = 0;
+    if (lane < 32u) byte = (uint8_t)(k->st[lane >> 3] >> (8 * (lane & 7u)));
+    lds_wave_sync();
+    if (lane < 25u) k->st[lane] = 0;
+    if (lane < 32u) { k->obuf[lane] = byte; k->blk[lane] = byte; }
+    if (lane == 0) { k->blen = 32; k->n_obuf = 32; }
+    lds_wave_sync();
 }
 __device__ __noinline__ uint32_t k_sample(KState* k) {
-    for (;;) {  // rejection sampling of a 31-bit value below P
+    for (;;) {  // rejection sampling of a 31-bit value below P; every lane follows the same path
         uint32_t v = 0;
         for (int i = 0; i < 4; i++) {
-            if (!k->n_obuf) k_flush(k);
-            v |= (uint32_t)k->obuf[--k->n_obuf] << (8 * i);
+            if (k->n_obuf == 0) k_flush(k);
+            const uint32_t nb = k->n_obuf - 1;
+            v |= (uint32_t)k->obuf[nb] << (8 * i);
+            if ((threadIdx.x & 63u) == 0) k->n_obuf = nb;
+            lds_wave_sync();
         }
         v &= 0x7fffffffu;
         if (v < bb::P) return bb::to_monty(v);
@@ -177,8 +218,7 @@ struct DevChal {
     // ---- the challenger interface: every lane of the wave calls these with the same arguments ----
     __device__ __forceinline__ void observe(uint32_t v) {  // a field element (Montgomery word)
         if (kind == HASH_KECCAK) {
-            if ((threadIdx.x & 63u) == 0)
-                for (int i = 0; i < 4; i++) k_observe_byte(k, (uint8_t)(v >> (8 * i)));
+            for (int i = 0; i < 4; i++) k_observe_byte(k, (uint8_t)(v >> (8 * i)));
             return;
         }
         n_out = 0;
@@ -189,11 +229,7 @@ struct DevChal {
     __device__ __forceinline__ void observe_n(const uint32_t* v, uint32_t n) { for (uint32_t i = 0; i < n; i++) observe(v[i]); }
     __device__ __forceinline__ void observe_ext(const bb::Ext& e) { observe_n(e.c, 4); }
     __device__ __forceinline__ uint32_t sample() {
-        if (kind == HASH_KECCAK) {
-            uint32_t v = 0;
-            if ((threadIdx.x & 63u) == 0) v = k_sample(k);
-            return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-        }
+        if (kind == HASH_KECCAK) return k_sample(k);
         if (n_in || !n_out) duplex();
         n_out--;
         return (uint32_t)__shfl((int)outb, (int)n_out, 16);

@@ -155,6 +155,12 @@ int p3hip_mmcs_commit_hash_dev(int hash, const uint32_t *const *d_mats, const si
 /* host-pointer convenience, as p3hip_mmcs_commit */
 int p3hip_mmcs_commit_hash(int hash, const uint32_t *const *mats, const size_t *heights, const size_t *widths,
                            size_t n_mats, uint32_t root_out[8], p3hip_tree_t **tree_out);
+/* Mmcs::commit into CALLER-PROVIDED digest-layer storage of p3hip_mmcs_layer_words(max height) 32-bit words (leaf layer
+ * first, 8 words per digest): nothing is allocated and nothing synchronises — the call only enqueues.  The tree borrows the
+ * storage and the matrices; read the root with p3hip_mmcs_root. */
+size_t p3hip_mmcs_layer_words(size_t max_height);
+int p3hip_mmcs_commit_into_dev(int hash, const uint32_t *const *d_mats, const size_t *heights, const size_t *widths,
+                               size_t n_mats, uint32_t *d_layers, p3hip_tree_t **tree_out, void *stream);
 /* KeccakF::permute_mut on n independent [u64; 25] states in device memory (p3-keccak's KeccakF, fib_air.rs:32) */
 int p3hip_keccak_f_dev(uint64_t *d_states, size_t n, void *stream);
 

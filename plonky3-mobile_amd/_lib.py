@@ -47,6 +47,9 @@ _SIGS = {
                                              C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
     "p3hip_mmcs_commit_hash": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
                                          C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "p3hip_mmcs_layer_words": (C.c_size_t, [C.c_size_t]),
+    "p3hip_mmcs_commit_into_dev": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
+                                             C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
     "p3hip_keccak_f_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "p3hip_mmcs_root": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "p3hip_mmcs_log_max_height": (C.c_size_t, [C.c_void_p]),

@@ -335,6 +335,23 @@ int p3hip_mmcs_commit_hash_dev(int hash, const uint32_t* const* d_mats, const si
     if (rc) { p3hip_mmcs_free(*tree_out); *tree_out = nullptr; }
     return rc;
 }
+// commit with CALLER-PROVIDED digest-layer storage (p3hip_mmcs_layer_words(max height) words): nothing is allocated, so
+// the call only enqueues (the fib_air prover commits this way into its arena)
+size_t p3hip_mmcs_layer_words(size_t max_height) { return mmcs_layer_words(max_height); }
+int p3hip_mmcs_commit_into_dev(int hash, const uint32_t* const* d_mats, const size_t* heights, const size_t* widths, size_t n_mats,
+                               uint32_t* d_layers, p3hip_tree_t** tree_out, void* stream) {
+    return guarded([&]() -> int {
+        if (!tree_out || !d_layers) return fail(ERR_BAD_ARG, "mmcs_commit_into: null argument");
+        Context* cx;
+        int rc = get_context(&cx);
+        if (rc) return rc;
+        Tree* t = nullptr;
+        rc = mmcs_commit((hipStream_t)stream, d_mats, heights, widths, n_mats, &t, d_layers, nullptr, hash);
+        if (rc) return rc;
+        *tree_out = new p3hip_tree{t};
+        return OK;
+    });
+}
 int p3hip_keccak_f_dev(uint64_t* d_states, size_t n, void* stream) {
     return guarded([&]() -> int {
         if (!d_states && n) return fail(ERR_BAD_ARG, "keccak_f: null states");

@@ -286,7 +286,7 @@ __global__ void poseidon2_f64_probe_kernel(const double* in, uint32_t* out, uint
 #pragma unroll
     for (int k = 0; k < 16; k++) s[k] = in[i * 16 + k];
     if (mode == 0) p2f::permute(s);
-    else if (mode == 1) p2f::internal_rounds(s);
+    else if (mode == 1) p2f::internal_rounds(s, p2f::magic_regs());
     else {
 #pragma unroll
         for (int k = 0; k < 16; k++) s[k] = p2f::reduce(s[k]);

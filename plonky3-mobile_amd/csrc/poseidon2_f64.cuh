@@ -40,11 +40,36 @@ __device__ __forceinline__ double add_scaled_pow2(double tot, double x, double i
     double fr = __builtin_amdgcn_fract(xt);
     return __fma_rn(fr, -PD, xt);
 }
-// x^7: x2 = x*x, x3 = x2*x, x4 = x3*x share xP = x / P; the last product pays for its own quotient estimate.
-__device__ __forceinline__ double sbox7(double x) {
-    double xP = x * PINV;
-    double x2 = mulmod_p(x, x, xP), x3 = mulmod_p(x, x2, xP), x4 = mulmod_p(x, x3, xP);
-    return mulmod(x3, x4);
+// The same product in FOUR ops, none of them a rounding instruction: with M = 1.5 * 2^52 (ulp 1),
+//   qb = fma(b, aP, M)           = M + rint(b * aP) = M + q                  (the classic magic-number rounding)
+//   c  = fma(-qb, P - 1, M * P)  = M - q (P - 1)                             (exact: a multiple of 2^27 below 2^71 plus M; M * P is a double)
+//   t  = fma(a, b, c)            = M + (ab - qP) + q                         (exact: M plus an integer below 2^40)
+//   t - qb                       = ab - qP                                   (exact difference of two integers below 2^53)
+// Valid for |b * aP| < 2^51 and |ab| < 2^76, i.e. for every product of the permutation (the largest S-box input is
+// 35 (P/2 + 1) < 2^36).  One op less than mulmod_p, two less than mulmod: the S-box drops from 23 to 19 fp64 ops.
+constexpr double MAGIC = 6755399441055744.0;                 // 1.5 * 2^52
+constexpr double MAGIC_P = 6755399441055744.0 * 2013265921.0;  // 45 * 2^78 + 3 * 2^51: exactly representable
+// Operand placement matters: a VOP3 fp64 op reads at most ONE scalar / literal operand on gfx950, and hipcc turns
+// fma(x, literal, constant) into v_fmac + a v_mov_b64 copy of the constant per use.  So M and M * P live in VGPR pairs
+// the compiler cannot rematerialise (MagicRegs, pinned once per kernel), -(P - 1) comes from an SGPR pair: every line
+// below is ONE v_fma_f64 / v_add_f64.
+struct MagicRegs { double m, mp; };
+__device__ __forceinline__ MagicRegs magic_regs() {
+    MagicRegs r{MAGIC, MAGIC_P};
+    asm volatile("" : "+v"(r.m), "+v"(r.mp));
+    return r;
+}
+__device__ __forceinline__ double mulmod_m(double a, double b, double aP, const MagicRegs& k, double neg_pm1) {
+    const double qb = __fma_rn(b, aP, k.m);
+    const double c = __fma_rn(qb, neg_pm1, k.mp);
+    const double t = __fma_rn(a, b, c);
+    return t - qb;
+}
+// x^7: x2 = x*x, x3 = x2*x, x4 = x3*x share xP = x / P; the last product x3 * x4 uses x3 / P.
+__device__ __forceinline__ double sbox7(double x, const MagicRegs& k, double neg_pm1, double pinv) {
+    const double xP = x * pinv;
+    const double x2 = mulmod_m(x, x, xP, k, neg_pm1), x3 = mulmod_m(x, x2, xP, k, neg_pm1), x4 = mulmod_m(x, x3, xP, k, neg_pm1);
+    return mulmod_m(x3, x4, x3 * pinv, k, neg_pm1);
 }
 
 struct ConstsF64 {
@@ -53,6 +78,7 @@ struct ConstsF64 {
     // multipliers of the internal diagonal that are not fp64 inline constants, kept in SGPRs (as literals the
     // compiler would pick v_fmac + a copy of the addend): 3, 15, 2^-2, 2^-3, 2^-4, 2^-8
     double k3, k15, i4, i8, i16, i256;
+    double neg_pm1, pinv;  // -(P - 1), 1 / P
 };
 constexpr uint32_t c_from_monty(uint32_t m) {  // m * 2^-32 mod P
     uint32_t t = m * bb::MU;
@@ -70,6 +96,7 @@ constexpr ConstsF64 make_consts() {
         }
     for (int r = 0; r < 13; r++) c.in[r] = (double)c_from_monty(P3_RC16_INTERNAL_MONTY[r]);
     c.k3 = 3.0; c.k15 = 15.0; c.i4 = 0.25; c.i8 = 0.125; c.i16 = 0.0625; c.i256 = 0.00390625;
+    c.neg_pm1 = -2013265920.0; c.pinv = 1.0 / 2013265921.0;
     return c;
 }
 static __device__ __constant__ ConstsF64 d_c = make_consts();
@@ -95,10 +122,11 @@ __device__ __forceinline__ void external_linear(double (&s)[16]) {
 // V = [-2, 1, 2, 1/2, 3, 4, -1/2, -3, -4, 2^-8, 1/4, 1/8, 2^-27, -2^-8, -1/16, -2^-27]; 2^-27 = -15 (mod P)
 // because P - 1 = 15 * 2^27.  The integer-multiplier lanes grow up to 15x per round: fold them back after
 // every fourth round (15^4 * 2^37 < 2^53: still exact integers); the fractional lanes stay below their entry bound.
-__device__ __forceinline__ void internal_rounds(double (&s)[16]) {
+__device__ __forceinline__ void internal_rounds(double (&s)[16], const MagicRegs& mk) {
+    const double npm1 = d_c.neg_pm1, pinv = d_c.pinv;
     const double k3 = d_c.k3, k15 = d_c.k15, i4 = d_c.i4, i8 = d_c.i8, i16 = d_c.i16, i256 = d_c.i256;
     auto internal_round = [&](int r) {
-        s[0] = sbox7(s[0] + d_c.in[r]);
+        s[0] = sbox7(s[0] + d_c.in[r], mk, npm1, pinv);
         double tot = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7])) +
                      (((s[8] + s[9]) + (s[10] + s[11])) + ((s[12] + s[13]) + (s[14] + s[15])));
         tot = reduce(tot);
@@ -135,18 +163,20 @@ __device__ __forceinline__ void internal_rounds(double (&s)[16]) {
 
 // |s_i| <= 2^33 on entry (canonical inputs or compress inputs < P); every intermediate stays below 2^53.
 __device__ __forceinline__ void permute(double (&s)[16]) {
+    const MagicRegs mk = magic_regs();
+    const double npm1 = d_c.neg_pm1, pinv = d_c.pinv;
     external_linear(s);  // <= 35 * 2^33 < 2^39
     _Pragma("clang loop unroll(disable)")
     for (int r = 0; r < 4; r++) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) s[i] = sbox7(s[i] + d_c.ext[r][i]);  // |.| <= P/2 + 1
+        for (int i = 0; i < 16; i++) s[i] = sbox7(s[i] + d_c.ext[r][i], mk, npm1, pinv);  // |.| <= P/2 + 1
         external_linear(s);                                                // <= 35 (P/2 + 1) < 2^36
     }
-    internal_rounds(s);
+    internal_rounds(s, mk);
     _Pragma("clang loop unroll(disable)")
     for (int r = 4; r < 8; r++) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) s[i] = sbox7(s[i] + d_c.ext[r][i]);
+        for (int i = 0; i < 16; i++) s[i] = sbox7(s[i] + d_c.ext[r][i], mk, npm1, pinv);
         external_linear(s);
     }
 }

@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--hash", choices=["poseidon2", "keccak"], default="poseidon2",
                     help="poseidon2 = BASELINE.json's configuration (default); keccak = the hashes the reference itself wires")
     args = ap.parse_args()
-    defaults = {"cfg2": dict(log_height=20, log_blowup=1, batch=32, threads=8, steps=10, warmup=2),
+    defaults = {"cfg2": dict(log_height=20, log_blowup=1, batch=32, threads=4, steps=10, warmup=2),
                 "cfg3": dict(log_height=24, log_blowup=2, batch=4, threads=2, steps=3, warmup=1),
                 "cfg5": dict(log_height=16, log_blowup=1, batch=1, threads=1, steps=10, warmup=2)}[args.workload]
     for k, v in defaults.items():

@@ -12,7 +12,7 @@
 #include <cstdio>
 #include <cstring>
 
-#include "bb31.cuh"
+#include "bb31.hip.h"
 #include "common.h"
 #include "mmcs.h"
 #include "prover.h"

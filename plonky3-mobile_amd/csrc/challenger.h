@@ -8,9 +8,9 @@
 #include <cstring>
 #include <vector>
 
-#include "bb31.cuh"
+#include "bb31.hip.h"
 #include "mmcs.h"
-#include "poseidon2.cuh"
+#include "poseidon2.hip.h"
 
 namespace p3 {
 

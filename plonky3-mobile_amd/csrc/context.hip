@@ -9,7 +9,7 @@
 //     an intermediate;
 //   - the bounded scale-table cache is only ever emptied at the top of an entry point (reserve_scale_slots), never
 //     between two fetches of one call.
-#include "bb31.cuh"
+#include "bb31.hip.h"
 #include "common.h"
 
 #include <memory>

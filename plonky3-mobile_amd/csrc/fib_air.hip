@@ -2,7 +2,7 @@
 //   generate_trace_rows (fib_air.rs:266-284): row 0 = (a, b), row i = (right_{i-1}, left_{i-1} + right_{i-1}).
 // The recurrence is serial on the CPU; here each lane jumps to its chunk with a 2x2 matrix power
 // (fast doubling over BabyBear) and then walks CHUNK rows, storing 8-byte rows coalesced per lane.
-#include "bb31.cuh"
+#include "bb31.hip.h"
 #include "common.h"
 
 namespace p3 {

@@ -11,10 +11,10 @@
 
 #include "common.h"
 #include "mmcs.h"
-#include "poseidon2.cuh"
-#include "poseidon2_coop.cuh"
-#include "poseidon2_f64.cuh"
-#include "keccak.cuh"
+#include "poseidon2.hip.h"
+#include "poseidon2_coop.hip.h"
+#include "poseidon2_f64.hip.h"
+#include "keccak.hip.h"
 
 namespace p3 {
 
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(256) tree_top_kernel(uint32_t* layer0, uint32_
 }
 
 
-// ---- fp64 variants of the two large one-state-per-lane kernels (poseidon2_f64.cuh): same digests, ~7 % fewer
+// ---- fp64 variants of the two large one-state-per-lane kernels (poseidon2_f64.hip.h): same digests, ~7 % fewer
 // issue cycles.  Memory stays Montgomery u32; conversion happens in registers at load/store.
 __global__ void __launch_bounds__(256) leaf_hash_f64_kernel(const uint32_t* mat, uint32_t width, uint64_t n_rows, uint32_t* digests) {
     uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(256) compress_layer_f64_kernel(const uint32_t*
     store_digest(next + i * 8, d);
 }
 
-// ---- lane-cooperative kernels for small layers (16 lanes per permutation, poseidon2_coop.cuh) ----
+// ---- lane-cooperative kernels for small layers (16 lanes per permutation, poseidon2_coop.hip.h) ----
 // next[i] = compress(prev[2i], prev[2i+1]); one 16-lane row per output digest.
 __global__ void __launch_bounds__(256) compress_coop_kernel(const uint32_t* prev, uint32_t* next, uint32_t n_out) {
     const uint32_t lane16 = threadIdx.x & 15;

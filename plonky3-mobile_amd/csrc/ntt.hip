@@ -12,7 +12,7 @@
 //     RUN/W consecutive rows), later passes are in place with a pre-twiddle w_{2^(s0+b)}^(rev(pt)*lo).
 //   DIF plan (natural in -> bit-reversed or natural out): top digit first, post-twiddle after the tile
 //     transform; zero padding and the coset/1/N scaling are folded into the first pass's loads.
-//   Narrow plan (ntt_narrow.cuh): the coset LDE of matrices up to 16 columns wide, bit-reversed output, 2^16..2^24
+//   Narrow plan (ntt_narrow.hip.h): the coset LDE of matrices up to 16 columns wide, bit-reversed output, 2^16..2^24
 //     rows — the fib_air trace and quotient commitments — as two digits per direction in three launches.
 //
 // Row-major H x W matrices of Montgomery words, exactly the buffers the reference uploads
@@ -20,7 +20,7 @@
 // (backend_vulkan.rs:881-942) with the same twiddle-table layout (:977-996: stage k at offset 2^k-1).
 #include <algorithm>
 
-#include "bb31.cuh"
+#include "bb31.hip.h"
 #include "common.h"
 
 namespace p3 {
@@ -134,8 +134,8 @@ __device__ __forceinline__ uint32_t two_level(const uint32_t* lo, const uint32_t
 }
 
 }  // namespace p3
-#include "ntt_fast.cuh"
-#include "ntt_narrow.cuh"
+#include "ntt_fast.hip.h"
+#include "ntt_narrow.hip.h"
 namespace p3 {
 
 // Decodes a copy-loop index into tile coordinates (pt, x), the global word offset and the natural row
@@ -854,7 +854,7 @@ int launch_narrow(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t
     return vw == 1 ? launch_narrow_v<K, 1>(cx, stream, a, b, blocks, gy) : launch_narrow_v<K, 2>(cx, stream, a, b, blocks, gy);
 }
 
-// Narrow-matrix coset LDE in three launches (ntt_narrow.cuh).  Returns 1 when the shape is not covered.
+// Narrow-matrix coset LDE in three launches (ntt_narrow.hip.h).  Returns 1 when the shape is not covered.
 int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* dst, uint32_t n, uint32_t added, uint32_t W,
                uint32_t shift, bool bit_reversed_out) {
     static int enabled = [] { const char* e = getenv("P3HIP_NTT_NARROW"); return e ? atoi(e) : 1; }();

@@ -1,6 +1,6 @@
 // Three-launch coset LDE for NARROW matrices (W = 2, 4, 8 or 16 columns: the fib_air trace and quotient shapes).
 //
-// The general plans (ntt.hip / ntt_fast.cuh) move one 32-bit word per lane and cut 2^n rows into three 6-8 stage
+// The general plans (ntt.hip / ntt_fast.hip.h) move one 32-bit word per lane and cut 2^n rows into three 6-8 stage
 // digits per direction: five launches for 2^20 -> 2^21, every one re-reading and re-writing the matrix.  Here the
 // height is cut into TWO digits (n = n1 + n2, 8..12 stages each), a lane moves a PAIR of columns (8-byte
 // accesses, one twiddle serves both columns; single columns for the small heights, where twice the waves matter

@@ -7,7 +7,7 @@
 // The diagonal is applied with shifts/adds: division by 2^k is exact Montgomery-style halving, using
 // P = 1 (mod 2^27): x/2^k = ((x + m) >> k) + 15*m << (27-k),  m = (-x) mod 2^k.
 #pragma once
-#include "bb31.cuh"
+#include "bb31.hip.h"
 #include "poseidon2_rc16.h"
 
 namespace p2 {

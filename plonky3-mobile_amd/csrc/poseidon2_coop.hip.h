@@ -1,12 +1,12 @@
 // Lane-cooperative Poseidon2 (width 16): ONE state spread over 16 consecutive lanes (= one DPP row), one
-// element per lane.  Same permutation as poseidon2.cuh, restructured for LATENCY: ~1.1k wave-instructions per
+// element per lane.  Same permutation as poseidon2.hip.h, restructured for LATENCY: ~1.1k wave-instructions per
 // permutation instead of ~7.3k, so the small Merkle layers (tree tops, FRI tail) whose time is one
 // permutation latency per level finish ~6x sooner.  It spends ~2.5x more lane-ops per permutation, so the
 // large layers keep the one-state-per-lane kernels.
 //   external layer: M4 inside each quad via DPP quad_perm, the 4-quad column sum via DPP row_ror:4/8/12
 //   internal layer: row sum by rotate-and-add (row_ror 8,4,2,1), diagonal as one Montgomery product per lane
 #pragma once
-#include "poseidon2.cuh"
+#include "poseidon2.hip.h"
 
 namespace p2c {
 

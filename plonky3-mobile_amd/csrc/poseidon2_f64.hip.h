@@ -1,4 +1,4 @@
-// Poseidon2 (same permutation as poseidon2.cuh) evaluated in DOUBLE PRECISION integer arithmetic.
+// Poseidon2 (same permutation as poseidon2.hip.h) evaluated in DOUBLE PRECISION integer arithmetic.
 // On gfx950 int32 and fp64 VALU ops issue at the same rate, but in fp64 a modular addition is ONE exact
 // v_add_f64 (no reduction while |v| < 2^53) instead of add/sub/min, which removes ~25% of the permutation's
 // instructions.  State elements are doubles holding integers congruent (mod P) to CANONICAL field values
@@ -6,7 +6,7 @@
 //   mulmod(a, b): h = a*b; l = fma(a, b, -h) (exact error); q = rint(h / P); r = fma(-q, P, h) + l
 //     exact for |a*b| < 2^84: h - qP is an integer below 2^32, l an integer below 2^31; result |r| < 1.1 P.
 #pragma once
-#include "poseidon2.cuh"
+#include "poseidon2.hip.h"
 
 namespace p2f {
 

@@ -35,7 +35,7 @@ class FibProver {
 };
 
 // The same prover for the HIDING half of the reference's configuration (native/src/fib_air.rs:40-65:
-// MerkleTreeHidingMmcs + HidingFriPcs, SmallRng::seed_from_u64(seed)); wire format version 2 (prover_hiding.inc).
+// MerkleTreeHidingMmcs + HidingFriPcs, SmallRng::seed_from_u64(seed)); wire format version 2 (prover_hiding.hip.inc).
 class FibHidingProver {
   public:
     FibHidingProver();

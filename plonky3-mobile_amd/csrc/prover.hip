@@ -15,16 +15,16 @@
 #include <memory>
 #include <cstring>
 
-#include "bb31.cuh"
+#include "bb31.hip.h"
 #include "challenger.h"
 #include "common.h"
-#include "keccak.cuh"
+#include "keccak.hip.h"
 #include "mmcs.h"
-#include "poseidon2.cuh"
-#include "poseidon2_f64.cuh"
+#include "poseidon2.hip.h"
+#include "poseidon2_f64.hip.h"
 #include "prover.h"
 #include "rng.h"
-#include "transcript.cuh"
+#include "transcript.hip.h"
 
 namespace p3 {
 
@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(256) grind_kernel(DevState* ds, uint32_t mask,
     uint32_t w = base + blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= bb::P) return;
     if (base + blockIdx.x * blockDim.x > *(volatile uint32_t*)&ds->grind_result) return;
-    // fp64 form of the permutation (poseidon2_f64.cuh: canonical values in doubles), as in the tree kernels
+    // fp64 form of the permutation (poseidon2_f64.hip.h: canonical values in doubles), as in the tree kernels
     const uint32_t pos = ds->n_in;  // the witness is the next observed element
     double s[16];
 #pragma unroll
@@ -337,7 +337,7 @@ __global__ void query_gather_kernel(const QTree* trees, uint32_t n_trees, const 
 }
 
 // ------------------------------------------------------------------------------------------------
-// transcript kernels: one wavefront each, between the bulk kernels, on the same stream (transcript.cuh)
+// transcript kernels: one wavefront each, between the bulk kernels, on the same stream (transcript.hip.h)
 // ------------------------------------------------------------------------------------------------
 // Proof staging buffer (device words; copied to the host once per proof):
 //   root_t[8] root_q[8] opened[8][4] froots[n_rounds][8] fpoly[fpl][4] witness status qidx[nq] (pad) slots[nq][slot_words]
@@ -904,4 +904,4 @@ void FibProver::reset_times() { im->times = StageTimes{}; }
 
 }  // namespace p3
 
-#include "prover_hiding.inc"
+#include "prover_hiding.hip.inc"

@@ -14,7 +14,7 @@
 //     where a host loop would.
 // Nothing synchronises with the host.  A fill that runs out of raw draws (probability far below 2^-100 with the margin
 // used) raises the error word instead of producing a short stream.
-#include "bb31.cuh"
+#include "bb31.hip.h"
 #include "common.h"
 #include "rng.h"
 

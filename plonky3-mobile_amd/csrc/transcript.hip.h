@@ -1,7 +1,7 @@
 // Device-resident Fiat-Shamir transcript of the fib_air prover: the challengers of challenger.h restated for ONE
 // WAVEFRONT, so that observe-root -> sample-challenge -> next kernel needs no host round trip.
 //   HASH_POSEIDON2  DuplexChallenger<BabyBear, Poseidon2-16, 16, 8>: the sponge state is spread over the 16 lanes of a
-//                   DPP row (poseidon2_coop.cuh: ~1.1k wave-instructions of latency per permutation instead of ~7k for a
+//                   DPP row (poseidon2_coop.hip.h: ~1.1k wave-instructions of latency per permutation instead of ~7k for a
 //                   single lane); every row of the wave carries the same state, so every lane sees the same results.
 //   HASH_KECCAK     SerializingChallenger32<BabyBear, HashChallenger<u8, Keccak256Hash, 32>> (native/src/fib_air.rs:53):
 //                   kept as a STREAMING sponge — the chaining digest and the observed bytes are absorbed as they arrive,
@@ -11,10 +11,10 @@
 // Same conventions as the host classes (p3-challenger 0.4.2 is absent: [UPSTREAM-RECALL], see challenger.h); the proofs
 // these produce are compared byte for byte with the host transcript of the CPU restatement in tests/.
 #pragma once
-#include "bb31.cuh"
-#include "keccak.cuh"
+#include "bb31.hip.h"
+#include "keccak.hip.h"
 #include "mmcs.h"
-#include "poseidon2_coop.cuh"
+#include "poseidon2_coop.hip.h"
 
 namespace p3 {
 

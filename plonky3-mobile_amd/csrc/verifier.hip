@@ -6,10 +6,10 @@
 #include <cstring>
 #include <vector>
 
-#include "bb31.cuh"
+#include "bb31.hip.h"
 #include "challenger.h"
 #include "common.h"
-#include "poseidon2.cuh"
+#include "poseidon2.hip.h"
 #include "prover.h"
 
 namespace p3 {
@@ -182,7 +182,7 @@ int verify_fib_air(const uint8_t* proof, size_t len, uint64_t a_pub, uint64_t b_
 }
 
 
-// ---- verifier of HIDING proofs (wire format version 2; prover_hiding.inc): p3_uni_stark::verify with SC::Pcs::ZK over
+// ---- verifier of HIDING proofs (wire format version 2; prover_hiding.hip.inc): p3_uni_stark::verify with SC::Pcs::ZK over
 // HidingFriPcs + MerkleTreeHidingMmcs as the reference configures them (native/src/fib_air.rs:40-72).  Leaves are the
 // opened values followed by their salts, matrix by matrix; the quotient is recomposed from the four blinded chunks
 // (the blinding cancels in sum_c zps_c(zeta) chunk_c(zeta)); every opened column, the random ones included, enters the

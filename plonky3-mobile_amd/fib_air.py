@@ -8,7 +8,7 @@ NUM_FIBONACCI_COLS = 2  # fib_air.rs:25
 
 
 def generate_trace_rows(a, b, n, device="cuda"):
-    """fib_air.rs:266-284 on the device: returns an (n, 2) int32 CUDA tensor of Montgomery words."""
+    """fib_air.rs:266-284 on the device: returns an (n, 2) int32 device tensor (torch device "cuda" = HIP on ROCm) of Montgomery words."""
     import torch
     if n & (n - 1):
         raise AssertionError("n must be a power of two")  # fib_air.rs:267 assert!(n.is_power_of_two())
@@ -235,7 +235,7 @@ class DeviceRng:
         _lib.check(_lib.lib().p3hip_rng_create(seed, C.byref(self._h)))
 
     def fill_field(self, n):
-        """The next n elements of the stream as an int32 CUDA tensor of Montgomery words (enqueued on the current stream)."""
+        """The next n elements of the stream as an int32 device tensor (torch device "cuda" = HIP on ROCm) of Montgomery words (enqueued on the current stream)."""
         import torch
         out = torch.empty((max(n, 1),), dtype=torch.int32, device="cuda")
         _lib.check(_lib.lib().p3hip_rng_fill_field_dev(self._h, C.c_void_p(out.data_ptr()), n, _stream_ptr()))

@@ -4,7 +4,7 @@ Same names and behaviour: BackendKind, set_backend_kind[_from_str], get_backend_
 take_last_error (gpu_dft.rs:14-68) and GpuDft with the TwoAdicSubgroupDft methods
 (gpu_dft.rs:70-115; idft/coset methods are Plonky3's provided trait methods).  Matrices are
 row-major (height, width) arrays of BabyBear Montgomery words: numpy uint32 on the host (the
-"e2e" path: upload, kernels, download) or torch int32/uint32 CUDA tensors (device-resident path,
+"e2e" path: upload, kernels, download) or torch int32/uint32 device tensors (torch device "cuda" is HIP on ROCm; device-resident path,
 enqueued on the current torch stream).
 
 Difference from the reference, on purpose: no CPU fallback.  gpu_dft.rs:100-112 swallows backend
@@ -109,7 +109,7 @@ class GpuDft:
         if _is_torch(mat):
             import torch
             if not mat.is_cuda or mat.dim() != 2 or mat.element_size() != 4:
-                raise ValueError("expected a 2-D CUDA tensor of 32-bit words")
+                raise ValueError("expected a 2-D device-resident tensor (torch device 'cuda' = HIP) of 32-bit words")
             mat = mat.contiguous()
             h, w = mat.shape
             out = torch.empty((out_rows, w), dtype=mat.dtype, device=mat.device)

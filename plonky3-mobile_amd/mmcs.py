@@ -12,7 +12,7 @@ from .gpu_dft import _is_torch, _stream_ptr, dev_u32
 
 
 def poseidon2_permute(states):
-    """n x 16 states (torch CUDA tensor in place, or numpy -> new array)."""
+    """n x 16 states (torch device tensor in place, or numpy -> new array)."""
     L = _lib.lib()
     if _is_torch(states):
         assert states.is_cuda and states.is_contiguous() and states.shape[-1] == 16
@@ -28,7 +28,7 @@ HASH_POSEIDON2, HASH_KECCAK = 0, 1
 
 
 def keccak_f(states):
-    """KeccakF::permute_mut on n x 25 u64 states (torch CUDA int64 tensor in place, or numpy uint64 -> new array)."""
+    """KeccakF::permute_mut on n x 25 u64 states (torch device int64 tensor in place, or numpy uint64 -> new array)."""
     import torch
     L = _lib.lib()
     if _is_torch(states):
@@ -83,7 +83,7 @@ class MerkleTreeMmcs:
         self.hash, self._kind = hash, kinds[hash]
 
     def commit(self, mats):
-        """Mmcs::commit.  mats: list of 2-D matrices (torch CUDA tensors stay resident; numpy arrays are
+        """Mmcs::commit.  mats: list of 2-D matrices (torch device tensors stay resident; numpy arrays are
         uploaded).  Returns (root as numpy uint32[8], MerkleTree)."""
         import torch
         L = _lib.lib()

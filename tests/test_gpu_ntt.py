@@ -214,7 +214,7 @@ def test_randomized_large_shapes(dft, oracle, p3):
                                         (22, 2, 1), (22, 4, 2), (16, 16, 1), (18, 16, 2), (19, 16, 1), (17, 2, 3), (20, 2, 3), (21, 2, 2),
                                         (23, 2, 1)])
 def test_narrow_three_launch_lde(dft, oracle, p3, log_h, w, ab):
-    """The two-digit, three-launch LDE for narrow matrices (ntt_narrow.cuh; W in {2, 4, 8, 16}, 2^16..2^24 rows,
+    """The two-digit, three-launch LDE for narrow matrices (ntt_narrow.hip.h; W in {2, 4, 8, 16}, 2^16..2^24 rows,
     bit-reversed output): every digit size 8..11 in both positions, every slot/row split, blowup 2, 4 and 8,
     against the oracle bit for bit.  (2^24 is covered by the cfg3 round-trip/proof tests.)"""
     rng = np.random.default_rng(1000 * log_h + 10 * w + ab)

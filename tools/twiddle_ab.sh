@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of north_star's "wavefront-shuffle twiddle broadcast" against the LDS broadcast reads the kernels use
-# (NARROW_TW_SHUFFLE, ntt_narrow.cuh), on the coset LDE of the fib_air trace (narrow_fwd2_kernel<10,..> and its two
+# (NARROW_TW_SHUFFLE, ntt_narrow.hip.h), on the coset LDE of the fib_air trace (narrow_fwd2_kernel<10,..> and its two
 # companions).  Build of the variant library: every csrc/*.hip with -DNARROW_TW_SHUFFLE=1 -> tools/_bin/libp3hip_twshuffle.so.
 # Run on the GPU box from the repo root; writes gpurun_out/r02_twiddle_ab.txt.
 ROOT=$(pwd); export TMPDIR=/tmp; OUT=$ROOT/gpurun_out

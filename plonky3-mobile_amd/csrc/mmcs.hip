@@ -150,6 +150,35 @@ __global__ void __launch_bounds__(256) leaf_hash_f64_kernel(const uint32_t* mat,
     for (int i = 0; i < 8; i++) d[i] = p2f::store_elem(s[i]);
     store_digest(digests + r * 8, d);
 }
+// the same sponge over the CONCATENATED rows of several matrices of one height (the (matrix, salt) pairs of the hiding
+// MMCS, or any multi-matrix commitment): element k of the row comes from the matrix whose column range holds k
+__global__ void __launch_bounds__(256) leaf_hash_f64_rowset_kernel(RowSet rs, uint64_t n_rows, uint32_t* digests) {
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    double s[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = 0.0;
+    uint32_t m = 0, off = 0;  // current matrix and column inside it
+    for (uint32_t k = 0; k < rs.total; k += 8) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (k + i < rs.total) {
+                while (off >= rs.width[m]) { m++; off = 0; }
+                s[i] = p2f::load_elem(rs.ptr[m][r * rs.width[m] + off]);
+                off++;
+            }
+        }
+        p2f::permute(s);
+        if (k + 8 < rs.total) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) s[i] = p2f::reduce(s[i]);
+        }
+    }
+    uint32_t d[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) d[i] = p2f::store_elem(s[i]);
+    store_digest(digests + r * 8, d);
+}
 __global__ void __launch_bounds__(256) compress_layer_f64_kernel(const uint32_t* prev, uint32_t* next, uint64_t n_out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_out) return;
@@ -581,6 +610,8 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
         } else if (rs.count == 1 && use_f64_tree()) {
             hipLaunchKernelGGL(leaf_hash_f64_kernel, dim3((uint32_t)((maxh + 255) / 256)), dim3(256), 0, stream, rs.ptr[0],
                                rs.width[0], maxh, t->layers);
+        } else if (use_f64_tree() && maxh >= COOP_MAX) {
+            hipLaunchKernelGGL(leaf_hash_f64_rowset_kernel, dim3((uint32_t)((maxh + 255) / 256)), dim3(256), 0, stream, rs, maxh, t->layers);
         } else {
             hipLaunchKernelGGL(leaf_hash_kernel, dim3((uint32_t)((maxh + 255) / 256)), dim3(256), 0, stream, rs, maxh, t->layers);
         }

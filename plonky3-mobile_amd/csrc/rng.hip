@@ -6,8 +6,9 @@
 //
 // A sequential generator with data-dependent rejections, in parallel:
 //   - the state transition of xoshiro256++ is linear over GF(2), so "advance by m steps" is a 256 x 256 bit matrix;
-//     the host builds J_k = T^(CHUNK * 2^k) once, lane t reaches the start of its chunk of CHUNK raw draws by
-//     applying J_k for the set bits of t (uniform loop, scalar matrix loads, per-lane select);
+//     the host builds J_k = T^(CHUNK * 2^k) once; a wave reaches its first chunk of CHUNK raw draws with the matrices
+//     of that chunk index's set bits and walks J_0 to the next 63, each product done by the whole wave (lane l owns
+//     four columns, xor-reduction over the wave: ~120 instructions instead of ~3000 for one lane);
 //   - pass 1 counts the accepted draws of every chunk, a one-workgroup scan turns the counts into output offsets,
 //     pass 2 replays the chunks and writes the accepted values to their places; the lane that writes the n-th value
 //     also writes the generator state right after that draw back to the stream, so the next fill continues exactly
@@ -23,8 +24,8 @@
 
 namespace p3 {
 
-constexpr uint32_t RNG_CHUNK_LOG = 10, RNG_CHUNK = 1u << RNG_CHUNK_LOG;  // raw draws per lane
-constexpr uint32_t RNG_MAX_JUMP = 20;                                     // up to 2^20 chunks per fill
+constexpr uint32_t RNG_CHUNK_LOG = 8, RNG_CHUNK = 1u << RNG_CHUNK_LOG;  // raw draws per lane
+constexpr uint32_t RNG_MAX_JUMP = 22;                                    // up to 2^22 chunks per fill
 
 // ---- host: SplitMix64 seeding and the GF(2) jump matrices ----
 void rng_seed_from_u64(uint64_t s[4], uint64_t state) {
@@ -88,24 +89,45 @@ const std::vector<uint64_t>& jump_matrices() {
 }  // namespace
 
 // ---- device ----
-__global__ void __launch_bounds__(256) rng_pass1_kernel(const DevRng* st, const uint64_t* __restrict__ jump, uint32_t n_chunks,
-                                                        uint32_t n_bits, uint64_t* states, uint32_t* counts) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t s[4] = {st->s[0], st->s[1], st->s[2], st->s[3]};
-    for (uint32_t k = 0; k < n_bits; k++) {  // uniform loop: every lane multiplies, lanes whose bit k is clear keep s
-        uint64_t r[4] = {0, 0, 0, 0};
-        const uint64_t* m = jump + (size_t)k * 256 * 4;
+// GF(2) matrix-vector product by ONE WAVE: the state is wave-uniform, lane l owns columns 4l .. 4l+3 (64 contiguous
+// bytes per lane: the 8 KB matrix is read once, coalesced), partial results are xor-reduced over the wave.
+__device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int mask) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, mask, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), mask, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ void wave_matvec(const uint64_t* __restrict__ m, uint64_t (&s)[4]) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t word = lane < 32u ? (lane < 16u ? s[0] : s[1]) : (lane < 48u ? s[2] : s[3]);
+    const uint32_t bit0 = (lane & 15u) * 4u;
+    uint64_t r[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int sw = 0; sw < 4; sw++) {
-            const uint64_t word = s[sw];
-            for (uint32_t b = 0; b < 64; b++) {
-                const uint64_t mask = 0ull - ((word >> b) & 1ull);
-                const uint64_t* col = m + ((size_t)sw * 64 + b) * 4;
+    for (uint32_t i = 0; i < 4; i++) {
+        const uint64_t mask = 0ull - ((word >> (bit0 + i)) & 1ull);
+        const uint64_t* col = m + ((size_t)lane * 4 + i) * 4;
 #pragma unroll
-                for (int w = 0; w < 4; w++) r[w] ^= col[w] & mask;
-            }
-        }
-        if ((t >> k) & 1u) { s[0] = r[0]; s[1] = r[1]; s[2] = r[2]; s[3] = r[3]; }
+        for (int w = 0; w < 4; w++) r[w] ^= col[w] & mask;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int w = 0; w < 4; w++) r[w] ^= shfl_xor64(r[w], off);
+#pragma unroll
+    for (int w = 0; w < 4; w++) s[w] = r[w];
+}
+// One wave per 64 consecutive chunks: the wave jumps to its first chunk with the matrices of the set bits of that
+// chunk index (bits >= 6), then walks J_0 = T^CHUNK sixty-three times, lane i keeping the i-th state; every lane then
+// counts the accepted draws of its chunk.
+__global__ void __launch_bounds__(64) rng_pass1_kernel(const DevRng* st, const uint64_t* __restrict__ jump, uint32_t n_chunks,
+                                                       uint32_t n_bits, uint64_t* states, uint32_t* counts) {
+    const uint32_t lane = threadIdx.x, first = blockIdx.x * 64u, t = first + lane;
+    uint64_t cur[4] = {st->s[0], st->s[1], st->s[2], st->s[3]};
+    for (uint32_t k = 6; k < n_bits; k++)
+        if ((first >> k) & 1u) wave_matvec(jump + (size_t)k * 256 * 4, cur);  // uniform branch
+    uint64_t s[4] = {cur[0], cur[1], cur[2], cur[3]};
+    const uint32_t last = n_chunks - first < 64u ? n_chunks - first : 64u;  // chunks of this wave
+    for (uint32_t i = 1; i < last; i++) {
+        wave_matvec(jump, cur);
+        if (lane == i) { s[0] = cur[0]; s[1] = cur[1]; s[2] = cur[2]; s[3] = cur[3]; }
     }
     if (t >= n_chunks) return;
 #pragma unroll
@@ -190,7 +212,7 @@ int rng_fill_field(Context& cx, hipStream_t stream, DevRng* st, uint32_t* out, u
     uint64_t* states = reinterpret_cast<uint64_t*>(workspace);
     uint32_t* counts = workspace + (size_t)chunks * 8;
     const uint32_t blocks = (chunks + 255) / 256;
-    hipLaunchKernelGGL(rng_pass1_kernel, dim3(blocks), dim3(256), 0, stream, st, cx.rng_jump, chunks, n_bits, states, counts);
+    hipLaunchKernelGGL(rng_pass1_kernel, dim3((chunks + 63) / 64), dim3(64), 0, stream, st, cx.rng_jump, chunks, n_bits, states, counts);
     P3_HIP(hipGetLastError());
     hipLaunchKernelGGL(rng_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, chunks);
     P3_HIP(hipGetLastError());

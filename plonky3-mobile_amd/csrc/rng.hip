@@ -7,8 +7,9 @@
 // A sequential generator with data-dependent rejections, in parallel:
 //   - the state transition of xoshiro256++ is linear over GF(2), so "advance by m steps" is a 256 x 256 bit matrix;
 //     the host builds J_k = T^(CHUNK * 2^k) once; a wave reaches its first chunk of CHUNK raw draws with the matrices
-//     of that chunk index's set bits and walks J_0 to the next 63, each product done by the whole wave (lane l owns
-//     four columns, xor-reduction over the wave: ~120 instructions instead of ~3000 for one lane);
+//     of that chunk index's set bits and walks J_0 to the next 63, each product done by the whole wave in a
+//     lane-interleaved basis (lane l owns four rows; the four ballots of the parity bits ARE the product: ~80
+//     instructions, no shuffle, instead of ~3000 for one lane);
 //   - pass 1 counts the accepted draws of every chunk, a one-workgroup scan turns the counts into output offsets,
 //     pass 2 replays the chunks and writes the accepted values to their places; the lane that writes the n-th value
 //     also writes the generator state right after that draw back to the stream, so the next fill continues exactly
@@ -76,10 +77,19 @@ const std::vector<uint64_t>& jump_matrices() {
             for (int k = 0; k < 4; k++) a->col[j].w[k] = s[k];
         }
         for (uint32_t i = 0; i < RNG_CHUNK_LOG; i++) { matsquare(*a, b.get()); a.swap(b); }
+        // Stored ROW-major in the lane-interleaved basis the device works in: permuted index p = 64 i + l stands for
+        // state bit 4 l + i (lane l of a wave owns bits 4l .. 4l+3), so that the four ballots of a wave ARE the four
+        // words of the product.  Row p_out = mask over permuted input indices; rows 64 i + l, i = 0..3, belong to lane l.
+        auto orig = [](int p) { return 4 * (p & 63) + (p >> 6); };
         flat.resize((size_t)RNG_MAX_JUMP * 256 * 4);
         for (uint32_t k = 0; k < RNG_MAX_JUMP; k++) {
-            for (int j = 0; j < 256; j++)
-                for (int w = 0; w < 4; w++) flat[((size_t)k * 256 + j) * 4 + w] = a->col[j].w[w];
+            for (int po = 0; po < 256; po++) {
+                uint64_t row[4] = {0, 0, 0, 0};
+                const int bo = orig(po);
+                for (int pi = 0; pi < 256; pi++)
+                    if ((a->col[orig(pi)].w[bo >> 6] >> (bo & 63)) & 1) row[pi >> 6] |= 1ull << (pi & 63);
+                for (int w = 0; w < 4; w++) flat[((size_t)k * 256 + po) * 4 + w] = row[w];
+            }
             matsquare(*a, b.get());
             a.swap(b);
         }
@@ -89,30 +99,61 @@ const std::vector<uint64_t>& jump_matrices() {
 }  // namespace
 
 // ---- device ----
-// GF(2) matrix-vector product by ONE WAVE: the state is wave-uniform, lane l owns columns 4l .. 4l+3 (64 contiguous
-// bytes per lane: the 8 KB matrix is read once, coalesced), partial results are xor-reduced over the wave.
-__device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int mask) {
-    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, mask, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), mask, 64);
-    return ((uint64_t)hi << 32) | lo;
+// GF(2) matrix-vector product by ONE WAVE in the lane-interleaved basis (see jump_matrices): the state is wave-uniform
+// (four 64-bit words in SGPRs), lane l holds the four rows that produce its bits, an output bit is the parity of
+// row & state, and the new state words are the four BALLOTS of those bits — no shuffle, no LDS, ~80 instructions.
+struct LaneRows { uint64_t r[4][4]; };
+__device__ __forceinline__ LaneRows load_rows(const uint64_t* __restrict__ m) {
+    LaneRows k;
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const ulonglong2* p = reinterpret_cast<const ulonglong2*>(m + ((size_t)i * 64 + lane) * 4);
+        const ulonglong2 a = p[0], b = p[1];
+        k.r[i][0] = a.x; k.r[i][1] = a.y; k.r[i][2] = b.x; k.r[i][3] = b.y;
+    }
+    return k;
 }
-__device__ __forceinline__ void wave_matvec(const uint64_t* __restrict__ m, uint64_t (&s)[4]) {
+__device__ __forceinline__ void wave_matvec(const LaneRows& k, uint64_t (&s)[4]) {
+    uint64_t out[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint64_t x = (k.r[i][0] & s[0]) ^ (k.r[i][1] & s[1]) ^ (k.r[i][2] & s[2]) ^ (k.r[i][3] & s[3]);
+        const uint32_t f = (uint32_t)x ^ (uint32_t)(x >> 32);
+        out[i] = __ballot((__builtin_popcount(f) & 1) != 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) s[i] = out[i];
+}
+// original basis -> lane-interleaved basis of a wave-uniform state: word i, bit l = original bit 4l + i
+__device__ __forceinline__ void to_interleaved(uint64_t (&s)[4]) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t word = lane < 32u ? (lane < 16u ? s[0] : s[1]) : (lane < 48u ? s[2] : s[3]);
     const uint32_t bit0 = (lane & 15u) * 4u;
-    uint64_t r[4] = {0, 0, 0, 0};
+    uint64_t out[4];
 #pragma unroll
-    for (uint32_t i = 0; i < 4; i++) {
-        const uint64_t mask = 0ull - ((word >> (bit0 + i)) & 1ull);
-        const uint64_t* col = m + ((size_t)lane * 4 + i) * 4;
+    for (uint32_t i = 0; i < 4; i++) out[i] = __ballot(((word >> (bit0 + i)) & 1ull) != 0);
 #pragma unroll
-        for (int w = 0; w < 4; w++) r[w] ^= col[w] & mask;
-    }
+    for (int i = 0; i < 4; i++) s[i] = out[i];
+}
+// lane-interleaved -> original basis, per lane (each lane its own state): original word W = bits 4l + i of the
+// interleaved words for l = 16W .. 16W + 15, i.e. a 4-way bit interleave of four 16-bit pieces
+__device__ __forceinline__ uint64_t spread16(uint64_t x) {  // bit k of x (k < 16) -> bit 4k
+    x &= 0xffffull;
+    x = (x | (x << 24)) & 0x000000ff000000ffull;
+    x = (x | (x << 12)) & 0x000f000f000f000full;
+    x = (x | (x << 6)) & 0x0303030303030303ull;
+    x = (x | (x << 3)) & 0x1111111111111111ull;
+    return x;
+}
+__device__ __forceinline__ void from_interleaved(uint64_t (&s)[4]) {
+    uint64_t out[4];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
+    for (int w = 0; w < 4; w++)
+        out[w] = spread16(s[0] >> (16 * w)) | (spread16(s[1] >> (16 * w)) << 1) | (spread16(s[2] >> (16 * w)) << 2) |
+                 (spread16(s[3] >> (16 * w)) << 3);
 #pragma unroll
-        for (int w = 0; w < 4; w++) r[w] ^= shfl_xor64(r[w], off);
-#pragma unroll
-    for (int w = 0; w < 4; w++) s[w] = r[w];
+    for (int w = 0; w < 4; w++) s[w] = out[w];
 }
 // One wave per 64 consecutive chunks: the wave jumps to its first chunk with the matrices of the set bits of that
 // chunk index (bits >= 6), then walks J_0 = T^CHUNK sixty-three times, lane i keeping the i-th state; every lane then
@@ -121,15 +162,18 @@ __global__ void __launch_bounds__(64) rng_pass1_kernel(const DevRng* st, const u
                                                        uint32_t n_bits, uint64_t* states, uint32_t* counts) {
     const uint32_t lane = threadIdx.x, first = blockIdx.x * 64u, t = first + lane;
     uint64_t cur[4] = {st->s[0], st->s[1], st->s[2], st->s[3]};
+    to_interleaved(cur);
+    const LaneRows j0 = load_rows(jump);
     for (uint32_t k = 6; k < n_bits; k++)
-        if ((first >> k) & 1u) wave_matvec(jump + (size_t)k * 256 * 4, cur);  // uniform branch
+        if ((first >> k) & 1u) wave_matvec(load_rows(jump + (size_t)k * 256 * 4), cur);  // uniform branch
     uint64_t s[4] = {cur[0], cur[1], cur[2], cur[3]};
     const uint32_t last = n_chunks - first < 64u ? n_chunks - first : 64u;  // chunks of this wave
     for (uint32_t i = 1; i < last; i++) {
-        wave_matvec(jump, cur);
+        wave_matvec(j0, cur);
         if (lane == i) { s[0] = cur[0]; s[1] = cur[1]; s[2] = cur[2]; s[3] = cur[3]; }
     }
     if (t >= n_chunks) return;
+    from_interleaved(s);
 #pragma unroll
     for (int w = 0; w < 4; w++) states[(size_t)t * 4 + w] = s[w];
     uint32_t cnt = 0;

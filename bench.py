@@ -153,8 +153,14 @@ def main():
     # fewer GPUs than ranks (collectives then move host tensors).
     backend = os.environ.get("P3HIP_BENCH_BACKEND", "nccl")
     coll_dev = "cuda" if backend == "nccl" else "cpu"
-    if world > 1:
+    # P3HIP_BENCH_FORCE_DIST=1: take the multi-rank code path (process group, scatter, gather, all_reduce) even with
+    # one rank — the only way to put RCCL itself through this code on a one-GPU box.
+    use_dist = world > 1 or os.environ.get("P3HIP_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -173,33 +179,55 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     from plonky3_mobile_amd import batch as pbatch
     n_total = args.batch * world
-    sharded = args.workload != "cfg5" and world > 1
+    sharded = args.workload != "cfg5" and use_dist
     allow_local = os.environ.get("P3HIP_BENCH_ALLOW_LOCAL") == "1"
     coll_state = {"mode": ("rccl scatter/gather" if backend == "nccl" else backend + " scatter/gather (rehearsal, not RCCL)")
                   if sharded else ("none (single rank)" if world == 1 else "none (replicas only: one matrix per rank)")}
     if sharded and os.environ.get("P3HIP_BENCH_NO_GATHER"):
         coll_state["mode"] = "disabled by P3HIP_BENCH_NO_GATHER: local sharding only"
 
+    def descriptors(k):
+        inst = [(k * n_total + i, k * n_total + i + 1) for i in range(n_total)] if rank == 0 else []
+        return pbatch.scatter_descriptors(inst, device=coll_dev)
+
     def one_step(k):
         if not sharded:
             return job.step()
         # BASELINE configs[3]: rank 0 scatters the instance descriptors, every rank proves its shard
         # (instance i -> rank i mod world), the proof bytes are gathered back on rank 0.  No other collective.
+        # Order of collectives on every rank: scatter(k+1), gather(k) — the next step's descriptors are fetched
+        # and the previous step's proofs are collected WHILE this step's proofs are being computed; between two
+        # steps the host only enqueues one H2D copy and the gather.
         if "scatter/gather" in coll_state["mode"]:
             try:
-                inst = [(k * n_total + i, k * n_total + i + 1) for i in range(n_total)] if rank == 0 else []
-                mine = pbatch.scatter_descriptors(inst, device=coll_dev)
-                got = job.step([(i, a) for i, a, _ in mine])
-                # the gather of this step's proofs overlaps the next step's proving; the previous one is collected now
-                prev, coll_state["pending"] = coll_state.get("pending"), pbatch.gather_proofs_async(
-                    sorted(got.items()), n_total, device=coll_dev)
-                return prev.wait() if prev is not None else None
+                mine = coll_state.pop("next", None)
+                if mine is None:
+                    mine = descriptors(k)
+                rows = {i: r for r, (i, _, _) in enumerate(mine)}
+                width = coll_state.get("width")
+                sink = None
+                if width is not None:
+                    put = coll_state["gatherer"].open(len(mine), width)
+                    sink = lambda i, pf: put(rows[i], i, pf)
+                job.step_begin([(i, a) for i, a, _ in mine], sink)
+                prev = coll_state.pop("pending", None)
+                res = prev.wait(copy=False) if prev is not None else None
+                coll_state["next"] = descriptors(k + 1)
+                got = job.step_end()
+                if width is None:  # first step: the ranks agree on the slot width (proofs of one parameter set have one length)
+                    pend = pbatch.gather_proofs_async(sorted(got.items()), n_total, device=coll_dev)
+                    coll_state["width"] = pend.width
+                    coll_state["gatherer"] = pbatch.ProofGatherer(n_total, coll_dev)
+                else:
+                    pend = coll_state["gatherer"].launch()
+                coll_state["pending"] = pend
+                return res
             except Exception as e:
                 # A failed collective is FATAL: an N-GPU line must never be printed without RCCL having moved the
                 # batch.  P3HIP_BENCH_ALLOW_LOCAL=1 (debugging only) continues with local sharding and says so.
@@ -214,7 +242,7 @@ def main():
     def drain():
         pend = coll_state.pop("pending", None)
         if pend is not None:
-            pend.wait()
+            pend.wait(copy=False)
 
     for k in range(args.warmup):
         one_step(k)
@@ -227,7 +255,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ranks_info = [{"rank": rank, "local_rank": local_rank, "device_count": n_dev, "device": torch.cuda.current_device()}]
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -258,7 +286,7 @@ def main():
         "roofline": roof,
         "collectives": coll_state["mode"],
         "world_size": world,
-        "dist_backend": (backend + (" (= RCCL on ROCm)" if backend == "nccl" else "")) if world > 1 else None,
+        "dist_backend": (backend + (" (= RCCL on ROCm)" if backend == "nccl" else "")) if use_dist else None,
         "ranks": ranks_info,
         "parity": "proof bytes / digests are compared with the repo's C oracle (a restatement of upstream Plonky3 from "
                   "recall; pinned by reference code only for the DFT): self-consistent, upstream parity UNPINNED",
@@ -272,7 +300,7 @@ def main():
     job.close()
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

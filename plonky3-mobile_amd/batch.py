@@ -36,70 +36,127 @@ def scatter_descriptors(instances, device="cpu"):
 class _PendingGather:
     """An in-flight gather of one step's proofs (two async collectives); wait() returns the proofs on rank 0."""
 
-    def __init__(self, works, bufs, metas, n_total, keep):
+    def __init__(self, works, bufs, metas, n_total, keep, landed=None, event=None):
         self.works, self.bufs, self.metas, self.n_total, self.keep = works, bufs, metas, n_total, keep
+        self.landed, self.event = landed, event
 
-    def wait(self):
-        for w in self.works:
-            w.wait()
+    def wait(self, copy=True):
+        """Rank 0: all n_total proofs in instance order — bytes objects, or with copy=False uint8 views of the
+        receive buffer (valid until the gather after next reuses it).  Other ranks: None."""
+        if self.event is not None:
+            self.event.synchronize()  # the collectives and the device -> pinned host copies behind them
+        else:
+            for w in self.works:
+                w.wait()
         if self.bufs is None:
             return None
         out = [None] * self.n_total
-        for b, m in zip(self.bufs, self.metas):
-            b, m = b.cpu().numpy(), m.cpu().tolist()
+        bufs, metas = (self.landed if self.landed is not None else (self.bufs, self.metas))
+        for b, m in zip(bufs, metas):
+            b, m = b.numpy(), m.tolist()
             for k, (i, ln) in enumerate(m):
                 if i >= 0:
-                    out[i] = b[k, :ln].tobytes()
+                    out[i] = b[k, :ln].tobytes() if copy else b[k, :ln]
         return out
 
 
-_STAGING = {}
+class ProofGatherer:
+    """Double-buffered staging for the per-step gather of proof bytes to rank 0.
+
+    open(n_local, width) hands out a sink the prover threads call as sink(row, index, proof) the moment a proof is
+    serialised (the copy into the pinned buffer overlaps the other provers' GPU work); launch() enqueues ONE H2D copy
+    and the two gathers and returns at once.  On a GPU backend rank 0 also enqueues the copies of the received buffers
+    into pinned host memory and an event behind them, so wait() costs no device round trip on the critical path.
+    `width` (bytes per proof slot) must be the same on every rank: proofs of one parameter set have one length, so
+    the caller learns it from the first step (gather_proofs_async does the all_reduce) and passes it from then on."""
+
+    def __init__(self, n_total, device="cpu"):
+        self.n_total, self.device = n_total, str(device)
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.per = (n_total + self.world - 1) // self.world
+        self.slots, self.turn, self.cur = {}, 0, None
+
+    def _slot(self, width):
+        self.turn ^= 1
+        key = (width, self.turn)
+        ent = self.slots.get(key)
+        if ent is None:
+            gpu = self.device != "cpu"
+            h = torch.zeros((self.per, width), dtype=torch.uint8)
+            hm = torch.full((self.per, 2), -1, dtype=torch.int64)
+            ent = {"h": h.pin_memory() if gpu else h, "hm": hm.pin_memory() if gpu else hm}
+            if gpu:
+                ent["d"] = torch.empty((self.per, width), dtype=torch.uint8, device=self.device)
+                ent["dm"] = torch.empty((self.per, 2), dtype=torch.int64, device=self.device)
+                if self.rank == 0:
+                    ent["rb"] = [torch.empty_like(ent["d"]) for _ in range(self.world)]
+                    ent["rm"] = [torch.empty_like(ent["dm"]) for _ in range(self.world)]
+                    ent["lb"] = [torch.empty((self.per, width), dtype=torch.uint8).pin_memory() for _ in range(self.world)]
+                    ent["lm"] = [torch.empty((self.per, 2), dtype=torch.int64).pin_memory() for _ in range(self.world)]
+            elif self.rank == 0:
+                ent["rb"] = [torch.empty_like(ent["h"]) for _ in range(self.world)]
+                ent["rm"] = [torch.empty_like(ent["hm"]) for _ in range(self.world)]
+            self.slots[key] = ent
+        return ent
+
+    def open(self, n_local, width):
+        if n_local > self.per:
+            raise ValueError("%d local proofs for %d slots" % (n_local, self.per))
+        ent = self.cur = self._slot(width)
+        host, meta = ent["h"].numpy(), ent["hm"].numpy()
+        meta[:] = -1
+
+        def sink(row, index, proof):
+            if len(proof) > width:
+                raise ValueError("proof of %d bytes does not fit the agreed slot of %d" % (len(proof), width))
+            host[row, : len(proof)] = np.frombuffer(proof, dtype=np.uint8)
+            meta[row] = (index, len(proof))
+        return sink
+
+    def launch(self):
+        ent, self.cur = self.cur, None
+        if self.device == "cpu":
+            buf, meta = ent["h"], ent["hm"]
+        else:
+            buf, meta = ent["d"], ent["dm"]
+            buf.copy_(ent["h"], non_blocking=True)
+            meta.copy_(ent["hm"], non_blocking=True)
+        bufs, metas = (ent["rb"], ent["rm"]) if self.rank == 0 else (None, None)
+        works = [dist.gather(buf, bufs, dst=0, async_op=True), dist.gather(meta, metas, dst=0, async_op=True)]
+        landed = event = None
+        if self.device != "cpu":
+            for w in works:
+                w.wait()  # stream-ordered: the current stream waits, the host does not
+            if self.rank == 0:
+                for src, dst in zip(bufs + metas, ent["lb"] + ent["lm"]):
+                    dst.copy_(src, non_blocking=True)
+                landed = (ent["lb"], ent["lm"])
+            event = torch.cuda.Event()
+            event.record()
+        return _PendingGather(works, bufs, metas, self.n_total, ent, landed, event)
 
 
-def _staging(per, width, device):
-    """Two alternating (pinned host, device) staging pairs per shape: the previous step's gather may still be
-    reading one while the next step fills the other."""
-    key = (per, width, str(device))
-    ent = _STAGING.get(key)
-    if ent is None:
-        pairs = []
-        for _ in range(2):
-            h = torch.zeros((per, width), dtype=torch.uint8)
-            if str(device) != "cpu":
-                h = h.pin_memory()
-                pairs.append((h, torch.empty((per, width), dtype=torch.uint8, device=device)))
-            else:
-                pairs.append((h, h))
-        ent = _STAGING[key] = {"pairs": pairs, "turn": 0}
-    ent["turn"] ^= 1
-    return ent["pairs"][ent["turn"]]
+_GATHERERS = {}
 
 
-def gather_proofs_async(local, n_total, device="cpu"):
+def gather_proofs_async(local, n_total, device="cpu", width=None):
     """local: list of (index, proof bytes) of this rank.  Starts the gather to rank 0 and returns a handle whose
-    wait() gives, on rank 0, all n_total proofs in instance order (None elsewhere).  Proofs are staged in one host
-    buffer padded to the longest one (a single H2D copy), so the collective has a fixed shape; being asynchronous
-    it overlaps the next step's proving."""
-    world, rank = dist.get_world_size(), dist.get_rank()
-    per = (n_total + world - 1) // world
-    max_len = torch.tensor([max([len(p) for _, p in local], default=0)], dtype=torch.int64, device=device)
-    dist.all_reduce(max_len, op=dist.ReduceOp.MAX)
-    width = int(max_len.item())
-    hbuf, buf = _staging(per, width, device)
-    host = hbuf.numpy()
-    hmeta = np.full((per, 2), -1, dtype=np.int64)  # (instance index, length)
+    wait() gives, on rank 0, all n_total proofs in instance order (None elsewhere).  Without `width` the ranks
+    first agree on the longest proof (one all_reduce); the collective has a fixed shape and, being asynchronous,
+    overlaps the next step's proving."""
+    if width is None:
+        max_len = torch.tensor([max([len(p) for _, p in local], default=0)], dtype=torch.int64, device=device)
+        dist.all_reduce(max_len, op=dist.ReduceOp.MAX)
+        width = int(max_len.item())
+    g = _GATHERERS.get((n_total, str(device)))
+    if g is None:
+        g = _GATHERERS[(n_total, str(device))] = ProofGatherer(n_total, device)
+    sink = g.open(len(local), width)
     for k, (i, p) in enumerate(local):
-        host[k, : len(p)] = np.frombuffer(p, dtype=np.uint8)
-        host[k, len(p):] = 0
-        hmeta[k] = (i, len(p))
-    host[len(local):] = 0
-    if buf is not hbuf:
-        buf.copy_(hbuf, non_blocking=True)  # pinned -> device, ordered before the collective on the current stream
-    meta = torch.from_numpy(hmeta).to(device)
-    bufs = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
-    metas = [torch.empty_like(meta) for _ in range(world)] if rank == 0 else None
-    works = [dist.gather(buf, bufs, dst=0, async_op=True), dist.gather(meta, metas, dst=0, async_op=True)]
-    return _PendingGather(works, bufs, metas, n_total, (buf, meta))
+        sink(k, i, p)
+    pend = g.launch()
+    pend.width = width
+    return pend
 
 
 def gather_proofs(local, n_total, device="cpu"):

@@ -48,13 +48,17 @@ class _Worker(threading.Thread):
                     if self.stagger_s:
                         time.sleep(self.stagger_s)
                         self.stagger_s = 0.0
+                    jobs, sink = arg
                     done = []
                     while True:
                         try:
-                            i, a = arg.get_nowait()
+                            i, a = jobs.get_nowait()
                         except queue.Empty:
                             break
-                        done.append((i, self.prover.prove(a, a + 1)))
+                        pf = self.prover.prove(a, a + 1)
+                        if sink is not None:
+                            sink(i, pf)  # e.g. straight into the pinned staging row of the step's gather
+                        done.append((i, pf))
                     self.outbox.put(("ok", done))
                 elif kind == "stages":
                     self.outbox.put(("ok", self.prover.stage_breakdown()))
@@ -179,32 +183,41 @@ class FibAirJob:
             out["frac_source"] = "profiles/r02_pmc_poseidon2.json missing: no counter evidence committed yet"
         return out
 
-    def step(self, instances=None):
-        """Proves independent instances; default: (a, b) = (first+i, first+i+1) for i < batch.
-        `instances`: list of (slot, a) as dealt by batch.scatter_descriptors.  Returns {slot: proof bytes}
-        as a list ordered by slot when called with the default."""
+    def step_begin(self, instances=None, sink=None):
+        """Hands the step's instances to the prover threads and returns at once; step_end() joins them.
+        `sink(slot, proof bytes)` is called by the prover thread as soon as a proof is serialised."""
         jobs = queue.Queue()
         todo = instances if instances is not None else [(i, self.first + i) for i in range(self.batch)]
         for item in todo:
             jobs.put(item)
         for w in self.workers:
-            w.inbox.put(("prove", jobs))
+            w.inbox.put(("prove", (jobs, sink)))
+        self._open = instances is not None
+
+    def step_end(self):
         got = {}
         for w in self.workers:
             for i, pf in w.result():
                 got[i] = pf
-        if instances is not None:
+        if self._open:
             self.last = got
             return got
         res = [got[i] for i in range(self.batch)]
         self.last = res
         return res
 
+    def step(self, instances=None, sink=None):
+        """Proves independent instances; default: (a, b) = (first+i, first+i+1) for i < batch.
+        `instances`: list of (slot, a) as dealt by batch.scatter_descriptors.  Returns {slot: proof bytes}
+        as a list ordered by slot when called with the default."""
+        self.step_begin(instances, sink)
+        return self.step_end()
+
     def prove_one(self, a, b):
         w = self.workers[0]
         jobs = queue.Queue()
         jobs.put((0, a))
-        w.inbox.put(("prove", jobs))
+        w.inbox.put(("prove", (jobs, None)))
         assert b == a + 1
         return w.result()[0][1]
 

@@ -101,6 +101,72 @@ def test_async_gather_double_buffer_reuse_world2():
         assert allp == [_fake_proof_step(step, i, 10 * step + i, 10 * step + i + 1) for i in range(7)], step
 
 
+def _worker_pipelined(rank, world, port, q):
+    import threading
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_package
+    load_package()
+    from plonky3_mobile_amd import batch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # bench.py's steady state: collectives in the order scatter(k+1), gather(k) on every rank; the proofs of step k
+    # are written into the staging rows by "prover" threads through the sink; fixed slot width; rank 0 reads views.
+    n_total, width, results, pending = 7, 64, [], None
+    g = batch.ProofGatherer(n_total, "cpu")
+
+    def descriptors(step):
+        inst = [(10 * step + i, 10 * step + i + 1) for i in range(n_total)] if rank == 0 else []
+        return batch.scatter_descriptors(inst)
+
+    nxt = descriptors(0)
+    for step in range(6):
+        mine = nxt
+        put = g.open(len(mine), width)
+        ths = [threading.Thread(target=lambda r=r, i=i, a=a, b=b: put(r, i, b"S%d:%d:%d:%d" % (step, i, a, b) * (1 + i % 3)))
+               for r, (i, a, b) in enumerate(mine)]
+        [t.start() for t in ths]
+        if pending is not None:
+            res = pending.wait(copy=False)
+            results.append([bytes(x) for x in res] if res is not None else None)
+        nxt = descriptors(step + 1)
+        [t.join() for t in ths]
+        pending = g.launch()
+    res = pending.wait(copy=False)
+    results.append([bytes(x) for x in res] if res is not None else None)
+    try:
+        g.open(1, width)(0, 0, b"x" * (width + 1))
+        overflow = "accepted"
+    except ValueError:
+        overflow = "refused"
+    if rank == 0:
+        q.put((results, overflow))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_gatherer_world2():
+    """ProofGatherer as bench.py drives it: prefetched scatter, sink called from threads, fixed slot width, zero-copy
+    views on rank 0, six steps over the two staging slots; an oversized proof is refused, not truncated."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_pipelined, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    results, overflow = q.get(timeout=120)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert overflow == "refused"
+    assert len(results) == 6
+    for step, allp in enumerate(results):
+        assert allp == [b"S%d:%d:%d:%d" % (step, i, 10 * step + i, 10 * step + i + 1) * (1 + i % 3) for i in range(7)], step
+
+
 def test_shard_instances_partition():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import load_package

@@ -13,6 +13,8 @@ void rng_seed_from_u64(uint64_t s[4], uint64_t seed);  // SmallRng::seed_from_u6
 int rng_seed(hipStream_t stream, DevRng* st, uint64_t seed);
 // workspace (32-bit words, 8-byte aligned) a fill of up to n_max elements needs
 int rng_workspace_words(uint64_t n_max, size_t* words);
+// whether ONE fill may produce n elements (the jump matrices cover 2^22 chunks of 256 raw draws)
+bool rng_fill_supported(uint64_t n);
 // enqueue: out[0..n) = the next n field elements of the stream (Montgomery words), *st advanced exactly as a host loop
 // would leave it; *err |= 1 if the fill ran out of raw draws (does not happen with the margin used)
 int rng_fill_field(Context& cx, hipStream_t stream, DevRng* st, uint32_t* out, uint64_t n, uint32_t* workspace, uint32_t* err);

@@ -230,9 +230,13 @@ int rng_seed(hipStream_t stream, DevRng* st, uint64_t seed) {
     return OK;
 }
 
+static uint64_t fill_chunks(uint64_t n) {
+    const uint64_t raw = n + n / 8 + 64 * (uint64_t)RNG_CHUNK;
+    return (raw + RNG_CHUNK - 1) / RNG_CHUNK;
+}
+bool rng_fill_supported(uint64_t n) { return (fill_chunks(n) >> RNG_MAX_JUMP) == 0; }
 int rng_workspace_words(uint64_t n_max, size_t* words) {
-    const uint64_t raw = n_max + n_max / 8 + 64 * (uint64_t)RNG_CHUNK;
-    const uint64_t chunks = (raw + RNG_CHUNK - 1) / RNG_CHUNK;
+    const uint64_t chunks = fill_chunks(n_max);
     if (chunks >> RNG_MAX_JUMP) return fail(ERR_BAD_ARG, "rng: fill too large");
     *words = (size_t)chunks * 8 + (size_t)chunks + 16;  // states (4 x u64) + counts
     return OK;

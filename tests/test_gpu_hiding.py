@@ -71,6 +71,20 @@ def test_hiding_seed_changes_the_proof_not_the_statement(p3, oracle):
     assert p2 == oracle.prove_fib_air_hiding(0, 1, 8, ofp, seed=2)
 
 
+def test_hiding_one_fill_per_stream_equals_piecewise_fills(p3, oracle, monkeypatch):
+    """The prover draws each of the three streams in ONE fill; beyond 2^30 raw draws it falls back to a fill per
+    buffer (forced here through P3HIP_HIDING_PIECEWISE): same bytes either way, equal to the oracle's sequential draws."""
+    gfp, ofp = _fp(p3, oracle, 1, 0, 10, 6)
+    ref = oracle.prove_fib_air_hiding(3, 4, 11, ofp, hash=oracle.HASH_KECCAK, seed=1)
+    whole = p3.FibAirProver(11, params=gfp, hash="keccak", hiding=True, seed=1)
+    monkeypatch.setenv("P3HIP_HIDING_PIECEWISE", "1")
+    pieces = p3.FibAirProver(11, params=gfp, hash="keccak", hiding=True, seed=1)
+    monkeypatch.delenv("P3HIP_HIDING_PIECEWISE")
+    assert whole.prove(3, 4) == ref
+    assert pieces.prove(3, 4) == ref
+    whole.close(), pieces.close()
+
+
 def test_hiding_headline_size_verifies(p3, oracle):
     """2^18-row trace (randomized to 2^19, LDE 2^20), benchmark FRI parameters: the oracle's verifier accepts."""
     gfp, ofp = _fp(p3, oracle, 1, 0, 100, 16)

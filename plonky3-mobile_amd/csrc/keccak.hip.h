@@ -66,4 +66,37 @@ __device__ __forceinline__ void permute(uint64_t (&a)[25]) {
     for (int r = 0; r < 24; r++) round(a, d_rc[r]);
 }
 
+// Lane-cooperative form: state word i = x + 5y of one permutation lives in lane i of a HALF-wave (lanes 0..24 and
+// 32..56 of a wave carry two independent states; the other lanes carry don't-care values); theta / pi / chi move data
+// with wave shuffles inside the half.  About 50 wave-instructions per round instead of ~260 for one lane holding all 25
+// words: one permutation costs ~4 us of latency instead of ~13.  Every lane of the wave must call it.  Not inlined:
+// one copy per kernel.
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, uint32_t src) {
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, (int)src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), (int)src, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __noinline__ uint64_t f_coop(uint64_t a) {
+    const uint32_t lane = threadIdx.x & 63u, base = lane & 32u, sub = lane & 31u, l = sub < 25u ? sub : 0u, x = l % 5u, y = l / 5u;
+    const uint32_t col1 = base + x + 5u * ((y + 1u) % 5u), col2 = base + x + 5u * ((y + 2u) % 5u),
+                   col3 = base + x + 5u * ((y + 3u) % 5u), col4 = base + x + 5u * ((y + 4u) % 5u);
+    const uint32_t xm1 = base + (x + 4u) % 5u + 5u * y, xp1 = base + (x + 1u) % 5u + 5u * y, xp2 = base + (x + 2u) % 5u + 5u * y;
+    // pi: B[y' + 5 ((2x' + 3y') % 5)] = rot(A[x' + 5y']); the lane at (X, Y) therefore reads from x' = (X + 3Y) % 5, y' = X
+    const uint32_t pi_src = base + (x + 3u * y) % 5u + 5u * x;
+    constexpr uint8_t RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+    uint32_t rho = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 25; i++) rho = l == i ? RHO[i] : rho;
+    _Pragma("clang loop unroll(disable)")
+    for (int r = 0; r < 24; r++) {
+        const uint64_t c = a ^ shfl64(a, col1) ^ shfl64(a, col2) ^ shfl64(a, col3) ^ shfl64(a, col4);  // column parity
+        const uint64_t cp = shfl64(c, xp1);
+        a ^= shfl64(c, xm1) ^ ((cp << 1) | (cp >> 63));
+        const uint64_t rot = (a << rho) | (a >> ((64u - rho) & 63u));
+        const uint64_t bb = shfl64(rot, pi_src);
+        a = bb ^ (~shfl64(bb, xp1) & shfl64(bb, xp2));
+        if (sub == 0) a ^= d_rc[r];
+    }
+    return a;
+}
+
 }  // namespace kk

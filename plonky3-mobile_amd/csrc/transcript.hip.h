@@ -85,33 +85,9 @@ __device__ __forceinline__ void lds_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
-__device__ __forceinline__ uint64_t shfl64(uint64_t v, uint32_t src) {
-    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, (int)src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), (int)src, 64);
-    return ((uint64_t)hi << 32) | lo;
-}
-__device__ __noinline__ uint64_t keccak_f_coop(uint64_t a) {  // lanes >= 25 carry don't-care values
-    const uint32_t lane = threadIdx.x & 63u, l = lane < 25u ? lane : 0u, x = l % 5u, y = l / 5u;
-    const uint32_t col1 = x + 5u * ((y + 1u) % 5u), col2 = x + 5u * ((y + 2u) % 5u), col3 = x + 5u * ((y + 3u) % 5u),
-                   col4 = x + 5u * ((y + 4u) % 5u);
-    const uint32_t xm1 = (x + 4u) % 5u + 5u * y, xp1 = (x + 1u) % 5u + 5u * y, xp2 = (x + 2u) % 5u + 5u * y;
-    // pi: B[y' + 5 ((2x' + 3y') % 5)] = rot(A[x' + 5y']); the lane at (X, Y) therefore reads from x' = (X + 3Y) % 5, y' = X
-    const uint32_t pi_src = (x + 3u * y) % 5u + 5u * x;
-    constexpr uint8_t RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
-    uint32_t rho = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < 25; i++) rho = l == i ? RHO[i] : rho;
-    _Pragma("clang loop unroll(disable)")
-    for (int r = 0; r < 24; r++) {
-        const uint64_t c = a ^ shfl64(a, col1) ^ shfl64(a, col2) ^ shfl64(a, col3) ^ shfl64(a, col4);  // column parity
-        const uint64_t cp = shfl64(c, xp1);
-        a ^= shfl64(c, xm1) ^ ((cp << 1) | (cp >> 63));
-        const uint64_t rot = (a << rho) | (a >> ((64u - rho) & 63u));
-        const uint64_t bb = shfl64(rot, pi_src);
-        a = bb ^ (~shfl64(bb, xp1) & shfl64(bb, xp2));
-        if (lane == 0) a ^= kk::d_rc[r];
-    }
-    return a;
-}
+// the lane-cooperative permutation itself lives in keccak.hip.h (kk::f_coop: two states per wave, one per half-wave);
+// the transcript uses the lower half only
+__device__ __forceinline__ uint64_t keccak_f_coop(uint64_t a) { return kk::f_coop(a); }
 __device__ __noinline__ void k_absorb_block(KState* k) {
     const uint32_t lane = threadIdx.x & 63u;
     lds_wave_sync();

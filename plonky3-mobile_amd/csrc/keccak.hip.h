@@ -86,6 +86,9 @@ __device__ __noinline__ uint64_t f_coop(uint64_t a) {
     uint32_t rho = 0;
 #pragma unroll
     for (uint32_t i = 0; i < 25; i++) rho = l == i ? RHO[i] : rho;
+    // round constants: lane r of the wave keeps RC[r]; the round reads it with v_readlane (no scalar load in the loop)
+    const uint64_t rcv = d_rc[lane < 24u ? lane : 0u];
+    const uint32_t rc_lo = (uint32_t)rcv, rc_hi = (uint32_t)(rcv >> 32), first = sub == 0 ? 0xffffffffu : 0u;
     _Pragma("clang loop unroll(disable)")
     for (int r = 0; r < 24; r++) {
         const uint64_t c = a ^ shfl64(a, col1) ^ shfl64(a, col2) ^ shfl64(a, col3) ^ shfl64(a, col4);  // column parity
@@ -94,7 +97,8 @@ __device__ __noinline__ uint64_t f_coop(uint64_t a) {
         const uint64_t rot = (a << rho) | (a >> ((64u - rho) & 63u));
         const uint64_t bb = shfl64(rot, pi_src);
         a = bb ^ (~shfl64(bb, xp1) & shfl64(bb, xp2));
-        if (sub == 0) a ^= d_rc[r];
+        const uint32_t k_lo = (uint32_t)__builtin_amdgcn_readlane((int)rc_lo, r) & first, k_hi = (uint32_t)__builtin_amdgcn_readlane((int)rc_hi, r) & first;
+        a ^= ((uint64_t)k_hi << 32) | k_lo;
     }
     return a;
 }

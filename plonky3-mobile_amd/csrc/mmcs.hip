@@ -605,6 +605,7 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
     // 16-lane form costs ~3.4x the VALU work of a one-state-per-lane permutation) when other work fills the chip
     static const uint64_t COOP_MAX = [] { const char* e = getenv("P3HIP_COOP_MAX_LOG"); int v = e ? atoi(e) : 15; return (uint64_t)1 << (v < 7 ? 7 : (v > 15 ? 15 : v)); }();
     static const uint64_t KCOOP_IN = [] { const char* e = getenv("P3HIP_KECCAK_COOP_MAX_LOG"); int v = e ? atoi(e) : 12; return v <= 0 ? (uint64_t)0 : (uint64_t)1 << (v > 12 ? 12 : v); }();
+    static const uint32_t KCOOP_CHUNK_LOG = [] { const char* e = getenv("P3HIP_KECCAK_COOP_CHUNK_LOG"); int v = e ? atoi(e) : 4; return (uint32_t)(v < 1 ? 1 : (v > 6 ? 6 : v)); }();
     if (kind == HASH_KECCAK) {
         // one state per lane for the large layers, the lane-cooperative form (shuffles inside a half-wave) for the small ones
         RowSet rs0 = make_rowset(*t, maxh);
@@ -620,9 +621,9 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
                 const uint64_t n_in = t->layer_len[l - 1];
                 const bool coop = n_in <= KCOOP_IN;
                 uint32_t levels = 0;
-                while (levels < (coop ? 6u : 11u) && l + levels < t->layer_len.size() && !has_height(*t, t->layer_len[l + levels])) levels++;
+                while (levels < (coop ? KCOOP_CHUNK_LOG : 11u) && l + levels < t->layer_len.size() && !has_height(*t, t->layer_len[l + levels])) levels++;
                 if (!coop) while (levels > 1 && (n_in >> levels) < KCOOP_IN) levels--;
-                const uint32_t chunk = (uint32_t)std::min<uint64_t>(n_in, coop ? 64ull : 2048ull);  // per workgroup
+                const uint32_t chunk = (uint32_t)std::min<uint64_t>(n_in, coop ? 1ull << KCOOP_CHUNK_LOG : 2048ull);  // per workgroup
                 while ((1u << levels) > chunk) levels--;
                 if (coop)
                     hipLaunchKernelGGL(keccak_tree_levels_coop_kernel, dim3((uint32_t)(n_in / chunk)), dim3(std::max<uint32_t>(64, chunk * 16)), 0,

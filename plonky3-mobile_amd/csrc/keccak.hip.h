@@ -66,41 +66,68 @@ __device__ __forceinline__ void permute(uint64_t (&a)[25]) {
     for (int r = 0; r < 24; r++) round(a, d_rc[r]);
 }
 
-// Lane-cooperative form: state word i = x + 5y of one permutation lives in lane i of a HALF-wave (lanes 0..24 and
-// 32..56 of a wave carry two independent states; the other lanes carry don't-care values); theta / pi / chi move data
-// with wave shuffles inside the half.  About 50 wave-instructions per round instead of ~260 for one lane holding all 25
-// words: one permutation costs ~4 us of latency instead of ~13.  Every lane of the wave must call it.  Not inlined:
-// one copy per kernel.
-__device__ __forceinline__ uint64_t shfl64(uint64_t v, uint32_t src) {
-    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, (int)src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), (int)src, 64);
-    return ((uint64_t)hi << 32) | lo;
+// Lane-cooperative form, ONE state per wave: state word A[x + 5y] lives in lane x + 8y (x, y < 5; the other 39 lanes are
+// padding and hold zero between the steps).  With rows of eight, everything that moves along x (theta's D, chi) is a
+// DPP row shift inside a 16-lane row — the wrap-around x = 4 -> 0 is a second shift restricted to half the banks, and
+// the zero padding makes the two shifted copies simply XOR together; the column parity is one row_ror:8 plus the
+// gfx950 v_permlane32_swap / v_permlane16_swap pair; rho is a per-lane v_alignbit pair; only pi crosses lanes
+// arbitrarily (two ds_bpermute).  About 55 wave-instructions and ONE LDS round trip per round (the first version:
+// shuffles for everything, 18 ds_bpermute in five dependent stages) — a permutation costs ~4 us instead of ~9, against
+// ~13 us for one lane holding all 25 words.  Every lane of the wave must call it.  Not inlined: one copy per kernel.
+__device__ __forceinline__ uint32_t coop_index() {  // which state word this lane holds; 25 = padding lane
+    const uint32_t lane = threadIdx.x & 63u, x = lane & 7u, y = lane >> 3;
+    return (x < 5u && y < 5u) ? x + 5u * y : 25u;
+}
+template <int CTRL, int BANKS>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v) {  // lanes without a source (other row, disabled bank) read 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, BANKS, true);
+}
+constexpr int ROW_SHL = 0x100, ROW_SHR = 0x110, ROW_ROR = 0x120;
+__device__ __forceinline__ uint32_t wave_column_xor(uint32_t v) {  // XOR over the eight lanes x + 8y of a column, in every lane
+    const uint32_t p = v ^ dpp0<ROW_ROR + 8, 0xf>(v);
+    const auto s = __builtin_amdgcn_permlane32_swap(p, p, false, false);
+    const uint32_t u = s[0] ^ s[1];
+    const auto t = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return t[0] ^ t[1];
 }
 __device__ __noinline__ uint64_t f_coop(uint64_t a) {
-    const uint32_t lane = threadIdx.x & 63u, base = lane & 32u, sub = lane & 31u, l = sub < 25u ? sub : 0u, x = l % 5u, y = l / 5u;
-    const uint32_t col1 = base + x + 5u * ((y + 1u) % 5u), col2 = base + x + 5u * ((y + 2u) % 5u),
-                   col3 = base + x + 5u * ((y + 3u) % 5u), col4 = base + x + 5u * ((y + 4u) % 5u);
-    const uint32_t xm1 = base + (x + 4u) % 5u + 5u * y, xp1 = base + (x + 1u) % 5u + 5u * y, xp2 = base + (x + 2u) % 5u + 5u * y;
+    const uint32_t lane = threadIdx.x & 63u, x = lane & 7u, y = lane >> 3, idx = coop_index();
+    const uint32_t M = idx < 25u ? 0xffffffffu : 0u, first = lane == 0 ? 0xffffffffu : 0u;
     // pi: B[y' + 5 ((2x' + 3y') % 5)] = rot(A[x' + 5y']); the lane at (X, Y) therefore reads from x' = (X + 3Y) % 5, y' = X
-    const uint32_t pi_src = base + (x + 3u * y) % 5u + 5u * x;
-    constexpr uint8_t RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+    const int pi_addr = (int)(4u * (idx < 25u ? (x + 3u * y) % 5u + 8u * x : lane));
+    constexpr uint8_t RHO[26] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14, 0};
     uint32_t rho = 0;
 #pragma unroll
-    for (uint32_t i = 0; i < 25; i++) rho = l == i ? RHO[i] : rho;
-    // round constants: lane r of the wave keeps RC[r]; the round reads it with v_readlane (no scalar load in the loop)
-    const uint64_t rcv = d_rc[lane < 24u ? lane : 0u];
-    const uint32_t rc_lo = (uint32_t)rcv, rc_hi = (uint32_t)(rcv >> 32), first = sub == 0 ? 0xffffffffu : 0u;
+    for (uint32_t i = 0; i < 25; i++) rho = idx == i ? RHO[i] : rho;
+    // rotl64 by rho as (optional swap of the halves) + two v_alignbit by sh = (32 - rho % 32) % 32; rho = 0 is "swap, then rotate by 32"
+    const bool swap = rho >= 32u || rho == 0u;
+    const uint32_t sh = (32u - (rho & 31u)) & 31u;
+    const uint64_t rcv = d_rc[lane < 24u ? lane : 0u];  // lane r keeps RC[r]: read with v_readlane, no scalar load in the loop
+    const uint32_t rc_lo = (uint32_t)rcv, rc_hi = (uint32_t)(rcv >> 32);
+    uint32_t lo = (uint32_t)a & M, hi = (uint32_t)(a >> 32) & M;
     _Pragma("clang loop unroll(disable)")
     for (int r = 0; r < 24; r++) {
-        const uint64_t c = a ^ shfl64(a, col1) ^ shfl64(a, col2) ^ shfl64(a, col3) ^ shfl64(a, col4);  // column parity
-        const uint64_t cp = shfl64(c, xp1);
-        a ^= shfl64(c, xm1) ^ ((cp << 1) | (cp >> 63));
-        const uint64_t rot = (a << rho) | (a >> ((64u - rho) & 63u));
-        const uint64_t bb = shfl64(rot, pi_src);
-        a = bb ^ (~shfl64(bb, xp1) & shfl64(bb, xp2));
+        // theta
+        const uint32_t c_lo = wave_column_xor(lo), c_hi = wave_column_xor(hi);
+        const uint32_t m_lo = dpp0<ROW_SHR + 1, 0xf>(c_lo) ^ dpp0<ROW_SHL + 4, 0x5>(c_lo);  // C[x - 1]
+        const uint32_t m_hi = dpp0<ROW_SHR + 1, 0xf>(c_hi) ^ dpp0<ROW_SHL + 4, 0x5>(c_hi);
+        const uint32_t p_lo = dpp0<ROW_SHL + 1, 0xf>(c_lo) ^ dpp0<ROW_SHR + 4, 0xa>(c_lo);  // C[x + 1]
+        const uint32_t p_hi = dpp0<ROW_SHL + 1, 0xf>(c_hi) ^ dpp0<ROW_SHR + 4, 0xa>(c_hi);
+        lo = (lo ^ m_lo ^ __builtin_amdgcn_alignbit(p_lo, p_hi, 31)) & M;
+        hi = (hi ^ m_hi ^ __builtin_amdgcn_alignbit(p_hi, p_lo, 31)) & M;
+        // rho, then pi
+        const uint32_t l2 = swap ? hi : lo, h2 = swap ? lo : hi;
+        const uint32_t b_lo = (uint32_t)__builtin_amdgcn_ds_bpermute(pi_addr, (int)__builtin_amdgcn_alignbit(l2, h2, sh));
+        const uint32_t b_hi = (uint32_t)__builtin_amdgcn_ds_bpermute(pi_addr, (int)__builtin_amdgcn_alignbit(h2, l2, sh));
+        // chi
+        const uint32_t b1_lo = dpp0<ROW_SHL + 1, 0xf>(b_lo) ^ dpp0<ROW_SHR + 4, 0xa>(b_lo), b1_hi = dpp0<ROW_SHL + 1, 0xf>(b_hi) ^ dpp0<ROW_SHR + 4, 0xa>(b_hi);
+        const uint32_t b2_lo = dpp0<ROW_SHL + 2, 0xf>(b_lo) ^ dpp0<ROW_SHR + 3, 0xf>(b_lo), b2_hi = dpp0<ROW_SHL + 2, 0xf>(b_hi) ^ dpp0<ROW_SHR + 3, 0xf>(b_hi);
+        // iota: RC[r] into lane 0
         const uint32_t k_lo = (uint32_t)__builtin_amdgcn_readlane((int)rc_lo, r) & first, k_hi = (uint32_t)__builtin_amdgcn_readlane((int)rc_hi, r) & first;
-        a ^= ((uint64_t)k_hi << 32) | k_lo;
+        lo = ((b_lo ^ (~b1_lo & b2_lo)) & M) ^ k_lo;
+        hi = ((b_hi ^ (~b1_hi & b2_hi)) & M) ^ k_hi;
     }
-    return a;
+    return ((uint64_t)hi << 32) | lo;
 }
 
 }  // namespace kk

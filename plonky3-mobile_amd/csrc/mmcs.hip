@@ -461,31 +461,31 @@ __global__ void __launch_bounds__(1024) keccak_tree_levels_kernel(uint32_t* laye
         n_layer >>= 1;
     }
 }
-// The last levels of a Keccak tree with the lane-cooperative permutation (kk::f_coop): a workgroup of 16 waves holds a
-// chunk of <= 64 consecutive digests in LDS and reduces it by up to six levels, one compression per HALF-wave, every
-// intermediate layer written to HBM.  A level costs ~4 us instead of the ~13 us of the one-state-per-lane kernel
-// above, at ~6x its lane-instructions — so only layers of <= 2^12 digests come here (mmcs_commit).
+// The last levels of a Keccak tree with the lane-cooperative permutation (kk::f_coop, one compression per WAVE): a
+// workgroup of up to 16 waves holds a chunk of <= 32 consecutive digests in LDS and reduces it by up to five levels,
+// every intermediate layer written to HBM.  A level costs ~4 us instead of the ~13 us of the one-state-per-lane kernel
+// above, at several times its lane-instructions — so only layers of <= 2^12 digests come here (mmcs_commit).
 __global__ void __launch_bounds__(1024) keccak_tree_levels_coop_kernel(uint32_t* layer0, uint32_t n_in, uint32_t chunk, uint32_t levels,
                                                                        uint32_t* root_copy) {
-    __shared__ uint64_t lds[64 * 4];
-    const uint32_t tid = threadIdx.x, blk = blockIdx.x, hw = tid >> 5, sub = tid & 31u;
+    __shared__ uint64_t lds[32 * 4];
+    const uint32_t tid = threadIdx.x, blk = blockIdx.x, wv = tid >> 6, idx = kk::coop_index();
     if (tid < chunk * 4) lds[tid] = reinterpret_cast<const uint64_t*>(layer0)[(size_t)blk * chunk * 4 + tid];
     __syncthreads();
     uint64_t* out = reinterpret_cast<uint64_t*>(layer0) + (size_t)n_in * 4;  // next layer
     uint32_t n_layer = n_in >> 1;                                             // its length
     for (uint32_t k = 0, n = chunk; k < levels; k++, n >>= 1) {
         const uint32_t half = n >> 1;
-        const bool wave_act = (tid >> 6) * 2 < half;  // uniform over the wave: both shuffle halves stay converged
+        const bool act = wv < half;  // uniform over the wave
         uint64_t a = 0;
-        if (wave_act) {
-            a = (hw < half && sub < 8) ? lds[hw * 8 + sub] : 0ull;
+        if (act) {
+            a = idx < 8u ? lds[wv * 8 + idx] : 0ull;
             a = kk::f_coop(a);
         }
         __syncthreads();
-        if (wave_act && hw < half && sub < 4) {
-            lds[hw * 4 + sub] = a;
-            out[((size_t)blk * half + hw) * 4 + sub] = a;
-            if (n_layer == 1 && root_copy) reinterpret_cast<uint64_t*>(root_copy)[sub] = a;
+        if (act && idx < 4u) {
+            lds[wv * 4 + idx] = a;
+            out[((size_t)blk * half + wv) * 4 + idx] = a;
+            if (n_layer == 1 && root_copy) reinterpret_cast<uint64_t*>(root_copy)[idx] = a;
         }
         __syncthreads();
         out += (size_t)n_layer * 4;
@@ -604,8 +604,12 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
     // P3HIP_COOP_MAX_LOG: 15 minimises a single tree's latency; lower values spend fewer lane-instructions (the
     // 16-lane form costs ~3.4x the VALU work of a one-state-per-lane permutation) when other work fills the chip
     static const uint64_t COOP_MAX = [] { const char* e = getenv("P3HIP_COOP_MAX_LOG"); int v = e ? atoi(e) : 15; return (uint64_t)1 << (v < 7 ? 7 : (v > 15 ? 15 : v)); }();
-    static const uint64_t KCOOP_IN = [] { const char* e = getenv("P3HIP_KECCAK_COOP_MAX_LOG"); int v = e ? atoi(e) : 12; return v <= 0 ? (uint64_t)0 : (uint64_t)1 << (v > 12 ? 12 : v); }();
-    static const uint32_t KCOOP_CHUNK_LOG = [] { const char* e = getenv("P3HIP_KECCAK_COOP_CHUNK_LOG"); int v = e ? atoi(e) : 4; return (uint32_t)(v < 1 ? 1 : (v > 6 ? 6 : v)); }();
+    static const uint64_t KCOOP_IN = [] { const char* e = getenv("P3HIP_KECCAK_COOP_MAX_LOG"); int v = e ? atoi(e) : 12; return v <= 0 ? (uint64_t)0 : (uint64_t)1 << (v > 15 ? 15 : v); }();
+    // one-state-per-lane levels kernel: digests per workgroup.  A level costs one permutation's issue time (~13 us) per
+    // wave a SIMD holds, so ONE wave per workgroup (128 digests) spreads a layer of <= 2^15 digests over the whole chip;
+    // 2048 (sixteen waves on one CU) was 25 us per level
+    static const uint64_t KLANE_CHUNK = [] { const char* e = getenv("P3HIP_KECCAK_LANE_CHUNK_LOG"); int v = e ? atoi(e) : 7; return (uint64_t)1 << (v < 7 ? 7 : (v > 11 ? 11 : v)); }();
+    static const uint32_t KCOOP_CHUNK_LOG = [] { const char* e = getenv("P3HIP_KECCAK_COOP_CHUNK_LOG"); int v = e ? atoi(e) : 4; return (uint32_t)(v < 1 ? 1 : (v > 5 ? 5 : v)); }();
     if (kind == HASH_KECCAK) {
         // one state per lane for the large layers, the lane-cooperative form (shuffles inside a half-wave) for the small ones
         RowSet rs0 = make_rowset(*t, maxh);
@@ -616,17 +620,17 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
             RowSet rs = make_rowset(*t, len);
             if (len < COOP_MAX && !rs.count) {
                 // as many injection-free levels as one launch may take.  Layers of <= 2^12 digests (P3HIP_KECCAK_COOP_MAX_LOG,
-                // 0 = never) go through the lane-cooperative kernel, six levels per launch at ~4 us each; above that one state
+                // 0 = never) go through the lane-cooperative kernel, 2^P3HIP_KECCAK_COOP_CHUNK_LOG digests per workgroup; above that one state
                 // per lane, chunks of up to 2048 digests per workgroup, stopping where the cooperative kernel takes over
                 const uint64_t n_in = t->layer_len[l - 1];
                 const bool coop = n_in <= KCOOP_IN;
                 uint32_t levels = 0;
                 while (levels < (coop ? KCOOP_CHUNK_LOG : 11u) && l + levels < t->layer_len.size() && !has_height(*t, t->layer_len[l + levels])) levels++;
                 if (!coop) while (levels > 1 && (n_in >> levels) < KCOOP_IN) levels--;
-                const uint32_t chunk = (uint32_t)std::min<uint64_t>(n_in, coop ? 1ull << KCOOP_CHUNK_LOG : 2048ull);  // per workgroup
+                const uint32_t chunk = (uint32_t)std::min<uint64_t>(n_in, coop ? 1ull << KCOOP_CHUNK_LOG : KLANE_CHUNK);  // per workgroup
                 while ((1u << levels) > chunk) levels--;
                 if (coop)
-                    hipLaunchKernelGGL(keccak_tree_levels_coop_kernel, dim3((uint32_t)(n_in / chunk)), dim3(std::max<uint32_t>(64, chunk * 16)), 0,
+                    hipLaunchKernelGGL(keccak_tree_levels_coop_kernel, dim3((uint32_t)(n_in / chunk)), dim3(std::max<uint32_t>(64, chunk * 32)), 0,
                                        stream, t->layers + t->layer_off[l - 1], (uint32_t)n_in, chunk, levels, root_copy);
                 else
                     hipLaunchKernelGGL(keccak_tree_levels_kernel, dim3((uint32_t)(n_in / chunk)), dim3(std::max<uint32_t>(64, chunk / 2)),

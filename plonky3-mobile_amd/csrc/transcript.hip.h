@@ -85,21 +85,19 @@ __device__ __forceinline__ void lds_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
-// the lane-cooperative permutation itself lives in keccak.hip.h (kk::f_coop: two states per wave, one per half-wave);
-// the transcript uses the lower half only
-__device__ __forceinline__ uint64_t keccak_f_coop(uint64_t a) { return kk::f_coop(a); }
+// the lane-cooperative permutation itself lives in keccak.hip.h (kk::f_coop: one state per wave, word x + 5y in lane x + 8y)
 __device__ __noinline__ void k_absorb_block(KState* k) {
-    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lane = threadIdx.x & 63u, idx = kk::coop_index();
     lds_wave_sync();
-    uint64_t a = lane < 25u ? k->st[lane] : 0ull;
-    if (lane < 17u) {
+    uint64_t a = idx < 25u ? k->st[idx] : 0ull;
+    if (idx < 17u) {
         uint64_t w = 0;
 #pragma unroll
-        for (int b = 0; b < 8; b++) w |= (uint64_t)k->blk[8 * lane + b] << (8 * b);
+        for (int b = 0; b < 8; b++) w |= (uint64_t)k->blk[8 * idx + b] << (8 * b);
         a ^= w;
     }
-    a = keccak_f_coop(a);
-    if (lane < 25u) k->st[lane] = a;
+    a = kk::f_coop(a);
+    if (idx < 25u) k->st[idx] = a;
     if (lane == 0) k->blen = 0;
     lds_wave_sync();
 }

@@ -224,12 +224,11 @@ __global__ void __launch_bounds__(256) leaf_coop_kernel(const uint32_t* mat, uin
 // and writes every intermediate layer to its place in HBM (layers are stored back to back).  16 lanes per
 // permutation; waves whose four lane-rows are all idle at a level skip the permutation.  When the last
 // level produces the root it is also written to `root_copy` (host-mapped) if given.
-__global__ void __launch_bounds__(1024) tree_levels_coop_kernel(uint32_t* layer_in, uint32_t n_in, uint32_t levels,
+__global__ void __launch_bounds__(1024) tree_levels_coop_kernel(uint32_t* layer_in, uint32_t n_in, uint32_t chunk, uint32_t levels,
                                                                 uint32_t* root_copy) {
     __shared__ uint32_t lds[128 * 8];
     const uint32_t tid = threadIdx.x, lane16 = tid & 15, grp = tid >> 4;
     const p2c::LaneConst lc = p2c::lane_constants(lane16);
-    const uint32_t chunk = n_in < 128u ? n_in : 128u;
     const uint32_t* src = layer_in + (size_t)blockIdx.x * chunk * 8;
     for (uint32_t i = tid; i < chunk * 8; i += blockDim.x) lds[i] = src[i];
     __syncthreads();
@@ -604,6 +603,9 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
     // P3HIP_COOP_MAX_LOG: 15 minimises a single tree's latency; lower values spend fewer lane-instructions (the
     // 16-lane form costs ~3.4x the VALU work of a one-state-per-lane permutation) when other work fills the chip
     static const uint64_t COOP_MAX = [] { const char* e = getenv("P3HIP_COOP_MAX_LOG"); int v = e ? atoi(e) : 15; return (uint64_t)1 << (v < 7 ? 7 : (v > 15 ? 15 : v)); }();
+    // digests per workgroup of the 16-lane cooperative Poseidon2 levels kernel: 2^5 = four waves, five levels per launch (2^7, sixteen
+    // waves on one CU and seven levels, measured 1.5 % slower at four provers)
+    static const uint32_t COOP_CHUNK_LOG = [] { const char* e = getenv("P3HIP_COOP_CHUNK_LOG"); int v = e ? atoi(e) : 5; return (uint32_t)(v < 3 ? 3 : (v > 7 ? 7 : v)); }();
     static const uint64_t KCOOP_IN = [] { const char* e = getenv("P3HIP_KECCAK_COOP_MAX_LOG"); int v = e ? atoi(e) : 12; return v <= 0 ? (uint64_t)0 : (uint64_t)1 << (v > 15 ? 15 : v); }();
     // one-state-per-lane levels kernel: digests per workgroup.  A level costs one permutation's issue time (~13 us) per
     // wave a SIMD holds, so ONE wave per workgroup (128 digests) spreads a layer of <= 2^15 digests over the whole chip;
@@ -669,15 +671,15 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
         if (!inject && len < COOP_MAX) {
             // as many injection-free levels as one launch may take (<= 7, stop before the next injected layer)
             uint32_t levels = 0;
-            while (levels < 7 && l + levels < t->layer_len.size() && !has_height(*t, t->layer_len[l + levels])) levels++;
+            while (levels < COOP_CHUNK_LOG && l + levels < t->layer_len.size() && !has_height(*t, t->layer_len[l + levels])) levels++;
             uint64_t n_in = t->layer_len[l - 1];
-            uint32_t chunk = n_in < 128 ? (uint32_t)n_in : 128u;
+            uint32_t chunk = (uint32_t)std::min<uint64_t>(n_in, 1ull << COOP_CHUNK_LOG);
             while ((1u << levels) > chunk) levels--;
             uint32_t blocks = (uint32_t)(n_in / chunk);
             uint32_t threads = std::max<uint32_t>(64, chunk * 8);
             bool makes_root = t->layer_len[l + levels - 1] == 1;
             hipLaunchKernelGGL(tree_levels_coop_kernel, dim3(blocks), dim3(threads), 0, stream, t->layers + t->layer_off[l - 1],
-                               (uint32_t)n_in, levels, makes_root ? root_copy : nullptr);
+                               (uint32_t)n_in, chunk, levels, makes_root ? root_copy : nullptr);
             P3_HIP(hipGetLastError());
             if (makes_root) t->root_copied = root_copy != nullptr;
             l += levels;

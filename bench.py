@@ -31,7 +31,7 @@ HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s s
 HBM_ACHIEVABLE_GBPS = 6300.0  # same guide: ~6.3 TB/s achievable
 
 
-def cpu_baseline_fib(log_height, job, hash_kind=0):
+def cpu_baseline_fib(log_height, job, hash_kind=0, hiding=False):
     """The reference CPU prover (Rust + Plonky3) cannot be built here, so the baseline is the
     repo's C restatement (oracle/, kind "port"), single-threaded like the reference build
     (native/Cargo.toml:32-43 enables no `parallel` feature), timed on this host on the SAME instance.
@@ -42,10 +42,12 @@ def cpu_baseline_fib(log_height, job, hash_kind=0):
     o.use_native()
     fp = o.FriParams(*[getattr(job.params, k) for k in ("log_blowup", "log_final_poly_len", "num_queries",
                                                          "proof_of_work_bits")])
-    sample_log = min(log_height, 20)
+    sample_log = min(log_height, 18 if hiding else 20)  # the hiding prover commits three times the columns on twice the rows
+    prove = (lambda *a, **k: o.prove_fib_air_hiding(*a, seed=1, **k)) if hiding else o.prove_fib_air
+    verify = o.verify_fib_air_hiding if hiding else o.verify_fib_air
     o.set_threads(1)
     t0 = time.perf_counter()
-    proof = o.prove_fib_air(0, 1, sample_log, fp, hash=hash_kind)
+    proof = prove(0, 1, sample_log, fp, hash=hash_kind)
     dt = time.perf_counter() - t0
     # the same port with its OpenMP loops (Merkle layers, quotient, openings, folds) on every host core
     # the GPU box gives one GPU's job a share of about 16 host cores whatever nproc says
@@ -56,7 +58,7 @@ def cpu_baseline_fib(log_height, job, hash_kind=0):
     cores = max(1, min(o.max_threads(), avail, int(os.environ.get("P3HIP_BENCH_CPU_THREADS", "16"))))
     o.set_threads(cores)
     t1 = time.perf_counter()
-    proof_mt = o.prove_fib_air(0, 1, sample_log, fp, hash=hash_kind)
+    proof_mt = prove(0, 1, sample_log, fp, hash=hash_kind)
     dt_mt = time.perf_counter() - t1
     o.set_threads(1)
     out = {"value": 1.0 / dt, "unit": "proofs/s", "cores": 1, "kind": "port",
@@ -69,13 +71,13 @@ def cpu_baseline_fib(log_height, job, hash_kind=0):
         gpu = job.prove_one(0, 1)
         out["proof_bytes_equal_to_gpu"] = bool(gpu == proof)
         out["oracle_verifier_accepts_gpu_proof"] = bool(
-            o.verify_fib_air(gpu, 0, 1, o.fib_public_x(0, 1, 1 << log_height), log_height, fp, hash=hash_kind) == 0)
+            verify(gpu, 0, 1, o.fib_public_x(0, 1, 1 << log_height), log_height, fp, hash=hash_kind) == 0)
     else:
         out["sample"] += " (the 2^%d instance itself takes minutes on one core: a 2^%d proof is the bounded sample)" % (
             log_height, sample_log)
         gpu = job.prove_one(0, 1)
         out["oracle_verifier_accepts_gpu_proof"] = bool(
-            o.verify_fib_air(gpu, 0, 1, o.fib_public_x(0, 1, 1 << log_height), log_height, fp, hash=hash_kind) == 0)
+            verify(gpu, 0, 1, o.fib_public_x(0, 1, 1 << log_height), log_height, fp, hash=hash_kind) == 0)
     return out
 
 
@@ -131,6 +133,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hash", choices=["poseidon2", "keccak"], default="poseidon2",
                     help="poseidon2 = BASELINE.json's configuration (default); keccak = the hashes the reference itself wires")
+    ap.add_argument("--hiding", action="store_true",
+                    help="the reference's hiding configuration (MerkleTreeHidingMmcs + HidingFriPcs, fib_air.rs:40-65); with --hash keccak "
+                         "this is exactly what the reference runs")
     args = ap.parse_args()
     defaults = {"cfg2": dict(log_height=20, log_blowup=1, batch=32, threads=4, steps=10, warmup=2),
                 "cfg3": dict(log_height=24, log_blowup=2, batch=4, threads=2, steps=3, warmup=1),
@@ -174,7 +179,7 @@ def main():
         job = bs.WideCommitJob(p3, args.log_height, args.log_blowup, hash=args.hash)
     else:
         job = bs.FibAirJob(p3, args.log_height, args.log_blowup, args.batch, first_instance=rank * args.batch,
-                           threads=args.threads, hash=args.hash, config_label={"cfg2": "configs[1]", "cfg3": "configs[2]"}.get(
+                           threads=args.threads, hash=args.hash, hiding=args.hiding, config_label={"cfg2": "configs[1]", "cfg3": "configs[2]"}.get(
                                args.workload if (args.log_height, args.log_blowup) == (defaults["log_height"], defaults["log_blowup"]) else ""))
 
     def barrier():
@@ -296,7 +301,7 @@ def main():
         if args.workload == "cfg5":
             out["cpu_baseline"] = cpu_baseline_wide(job)
         else:
-            out["cpu_baseline"] = cpu_baseline_fib(args.log_height, job, 1 if args.hash == "keccak" else 0)
+            out["cpu_baseline"] = cpu_baseline_fib(args.log_height, job, 1 if args.hash == "keccak" else 0, hiding=args.hiding)
     job.close()
     if rank == 0:
         print(json.dumps(out))

@@ -19,9 +19,9 @@ from .mmcs import MerkleTreeMmcs
 
 
 class _Worker(threading.Thread):
-    def __init__(self, device, log_height, params, stagger_s=0.0, hash="poseidon2"):
+    def __init__(self, device, log_height, params, stagger_s=0.0, hash="poseidon2", hiding=False):
         super().__init__(daemon=True)
-        self.hash = hash
+        self.hash, self.hiding = hash, hiding
         self.stagger_s = stagger_s
         self.device, self.log_height, self.params = device, log_height, params
         self.inbox, self.outbox = queue.Queue(), queue.Queue()
@@ -31,7 +31,7 @@ class _Worker(threading.Thread):
     def run(self):
         try:
             torch.cuda.set_device(self.device)
-            self.prover = FibAirProver(self.log_height, params=self.params, hash=self.hash)
+            self.prover = FibAirProver(self.log_height, params=self.params, hash=self.hash, hiding=self.hiding)
             self.outbox.put(("ready", None))
         except Exception as e:  # surfaced by the caller
             self.outbox.put(("error", e))
@@ -73,9 +73,9 @@ class _Worker(threading.Thread):
 
 
 class FibAirJob:
-    def __init__(self, p3, log_height, log_blowup, batch, first_instance=0, threads=4, hash="poseidon2", config_label=None):
+    def __init__(self, p3, log_height, log_blowup, batch, first_instance=0, threads=4, hash="poseidon2", config_label=None, hiding=False):
         self.p3 = p3
-        self.hash = hash
+        self.hash, self.hiding = hash, hiding
         self.config_label = config_label  # "configs[1]" / "configs[2]" when the size IS that BASELINE config
         self.device = torch.cuda.current_device()
         self.log_height, self.log_blowup, self.batch = log_height, log_blowup, batch
@@ -86,7 +86,7 @@ class FibAirJob:
         self.params = FriParameters(log_blowup=log_blowup)
         self.threads = max(1, min(threads, batch))
         stag = float(os.environ.get("P3HIP_BENCH_STAGGER_MS", "1.0")) * 1e-3
-        self.workers = [_Worker(self.device, log_height, self.params, stag * t, hash) for t in range(self.threads)]
+        self.workers = [_Worker(self.device, log_height, self.params, stag * t, hash, hiding) for t in range(self.threads)]
         for w in self.workers:
             w.result()
         self.last = None
@@ -102,6 +102,10 @@ class FibAirJob:
         return "proofs/s"
 
     def workload_name(self):
+        if self.hiding:
+            return ("fib_air 2^%d-row trace, the reference's own configuration%s: hiding MMCS (4 salt elements) + HidingFriPcs (4 random "
+                    "codewords), SmallRng streams seeded with 1 (fib_air.rs:28-65), blowup %d" % (
+                        self.log_height, " with its Keccak hashes" if self.hash == "keccak" else " but Poseidon2 hashes", 1 << self.log_blowup))
         if self.hash == "keccak":
             return ("fib_air 2^%d-row trace, BabyBear + the reference's own Keccak hashes (fib_air.rs:28-53, non-hiding), "
                     "blowup %d" % (self.log_height, 1 << self.log_blowup))
@@ -110,7 +114,7 @@ class FibAirJob:
 
     def config(self):
         return {"log_height": self.log_height, "width": 2, "log_blowup": self.log_blowup, "batch_per_gpu": self.batch,
-                "concurrent_provers_per_gpu": self.threads,
+                "concurrent_provers_per_gpu": self.threads, "hiding": self.hiding,
                 "fri": {"log_final_poly_len": self.params.log_final_poly_len, "num_queries": self.params.num_queries,
                         "proof_of_work_bits": self.params.proof_of_work_bits}}
 
@@ -140,7 +144,10 @@ class FibAirJob:
                 "concurrent_gbps": roof.get("concurrent_gbps"), "concurrent_streams": roof.get("concurrent_streams")}
 
     def extra_report(self):
-        return {"valu_roofline": self.poseidon2_roofline(), "stages_ms": self.stage_breakdown()}
+        out = {"valu_roofline": self.poseidon2_roofline()}
+        if not self.hiding:  # the hiding prover keeps no per-stage events
+            out["stages_ms"] = self.stage_breakdown()
+        return out
 
     def poseidon2_roofline(self):
         """The kernels that dominate a proof BY TIME are the Poseidon2 leaf / compression layers (12.6 M permutations per

@@ -137,7 +137,7 @@ def main():
                     help="the reference's hiding configuration (MerkleTreeHidingMmcs + HidingFriPcs, fib_air.rs:40-65); with --hash keccak "
                          "this is exactly what the reference runs")
     args = ap.parse_args()
-    defaults = {"cfg2": dict(log_height=20, log_blowup=1, batch=32, threads=4, steps=10, warmup=2),
+    defaults = {"cfg2": dict(log_height=20, log_blowup=1, batch=32, threads=4, steps=20, warmup=2),
                 "cfg3": dict(log_height=24, log_blowup=2, batch=4, threads=2, steps=3, warmup=1),
                 "cfg5": dict(log_height=16, log_blowup=1, batch=1, threads=1, steps=10, warmup=2)}[args.workload]
     for k, v in defaults.items():
@@ -201,62 +201,73 @@ def main():
         inst = [(k * n_total + i, k * n_total + i + 1) for i in range(n_total)] if rank == 0 else []
         return pbatch.scatter_descriptors(inst, device=coll_dev)
 
-    def one_step(k):
+    # Steps are PIPELINED (depth 1): step k + 1 is issued — its instances dealt to the prover threads' queue — before
+    # step k retires, so a prover that has finished its share of step k starts on step k + 1 at once instead of
+    # idling until the slowest proof of the step is done (the per-step join cost ~8 % at 32 proofs per step).  All K
+    # steps complete inside the timed region (the last one is retired and its proofs collected before the closing barrier).
+    # Multi-rank (BASELINE configs[3]): rank 0 scatters the instance descriptors, every rank proves its shard (instance i
+    # -> rank i mod world) with the prover threads writing each proof straight into the pinned staging row of the step's
+    # gather, the proof bytes are gathered back on rank 0.  Order of collectives on every rank: scatter(k+1), gather(k);
+    # the previous step's proofs are collected WHILE the next one is being proved.  No other collective.
+    use_gather = sharded and "scatter/gather" in coll_state["mode"]
+    if use_gather:
+        try:
+            width = torch.tensor([len(job.prove_one(0, 1))], dtype=torch.int64, device=coll_dev)
+            dist.all_reduce(width, op=dist.ReduceOp.MAX)  # proofs of one parameter set have one length: the slot width
+            coll_state["width"] = int(width.item())
+            coll_state["gatherer"] = pbatch.ProofGatherer(n_total, coll_dev)
+        except Exception as e:
+            print("bench.py: collective setup failed on rank %d: %r" % (rank, e), file=sys.stderr)
+            if not allow_local:
+                sys.stderr.flush()
+                os._exit(3)
+            use_gather = False
+            coll_state["mode"] = "FALLBACK to local sharding (collective failed: %s; P3HIP_BENCH_ALLOW_LOCAL=1)" % type(e).__name__
+
+    def issue(k):
         if not sharded:
-            return job.step()
-        # BASELINE configs[3]: rank 0 scatters the instance descriptors, every rank proves its shard
-        # (instance i -> rank i mod world), the proof bytes are gathered back on rank 0.  No other collective.
-        # Order of collectives on every rank: scatter(k+1), gather(k) — the next step's descriptors are fetched
-        # and the previous step's proofs are collected WHILE this step's proofs are being computed; between two
-        # steps the host only enqueues one H2D copy and the gather.
-        if "scatter/gather" in coll_state["mode"]:
-            try:
-                mine = coll_state.pop("next", None)
-                if mine is None:
-                    mine = descriptors(k)
-                rows = {i: r for r, (i, _, _) in enumerate(mine)}
-                width = coll_state.get("width")
-                sink = None
-                if width is not None:
-                    put = coll_state["gatherer"].open(len(mine), width)
-                    sink = lambda i, pf: put(rows[i], i, pf)
-                job.step_begin([(i, a) for i, a, _ in mine], sink)
-                prev = coll_state.pop("pending", None)
-                res = prev.wait(copy=False) if prev is not None else None
-                coll_state["next"] = descriptors(k + 1)
-                got = job.step_end()
-                if width is None:  # first step: the ranks agree on the slot width (proofs of one parameter set have one length)
-                    pend = pbatch.gather_proofs_async(sorted(got.items()), n_total, device=coll_dev)
-                    coll_state["width"] = pend.width
-                    coll_state["gatherer"] = pbatch.ProofGatherer(n_total, coll_dev)
-                else:
-                    pend = coll_state["gatherer"].launch()
-                coll_state["pending"] = pend
-                return res
-            except Exception as e:
-                # A failed collective is FATAL: an N-GPU line must never be printed without RCCL having moved the
-                # batch.  P3HIP_BENCH_ALLOW_LOCAL=1 (debugging only) continues with local sharding and says so.
-                print("bench.py: scatter/gather failed on rank %d: %r" % (rank, e), file=sys.stderr)
-                if not allow_local:
-                    sys.stderr.flush()
-                    os._exit(3)
-                coll_state["mode"] = "FALLBACK to local sharding (collective failed: %s; P3HIP_BENCH_ALLOW_LOCAL=1)" % type(e).__name__
-        mine = [(i, k * n_total + i) for i in pbatch.shard_instances(n_total, rank, world)]
-        return job.step(mine)
+            job.step_begin()
+            return None
+        if not use_gather:
+            job.step_begin([(i, k * n_total + i) for i in pbatch.shard_instances(n_total, rank, world)])
+            return None
+        mine = descriptors(k)
+        rows = {i: r for r, (i, _, _) in enumerate(mine)}
+        put, slot = coll_state["gatherer"].open(len(mine), coll_state["width"])
+        job.step_begin([(i, a) for i, a, _ in mine], lambda i, pf: put(rows[i], i, pf))
+        return slot
 
-    def drain():
-        pend = coll_state.pop("pending", None)
-        if pend is not None:
-            pend.wait(copy=False)
+    def retire(slot):
+        got = job.step_end()
+        if slot is None:
+            return got
+        prev, coll_state["pending"] = coll_state.get("pending"), coll_state["gatherer"].launch(slot)
+        return prev.wait(copy=False) if prev is not None else None
 
-    for k in range(args.warmup):
-        one_step(k)
-    drain()
+    def run_steps(first, count):
+        # A failed collective is FATAL: an N-GPU line must never be printed without RCCL having moved the batch.
+        try:
+            if count <= 0:
+                return
+            inflight = [issue(first)]
+            for k in range(first + 1, first + count):
+                inflight.append(issue(k))
+                retire(inflight.pop(0))
+            retire(inflight.pop(0))
+            pend = coll_state.pop("pending", None)
+            if pend is not None:
+                pend.wait(copy=False)  # the last step's proofs must be on rank 0 inside the timed region
+        except Exception as e:
+            if not use_gather:
+                raise
+            print("bench.py: scatter/gather failed on rank %d: %r" % (rank, e), file=sys.stderr)
+            sys.stderr.flush()
+            os._exit(3)
+
+    run_steps(0, args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        one_step(args.warmup + k)
-    drain()  # the last step's proofs must be on rank 0 inside the timed region
+    run_steps(args.warmup, args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     ranks_info = [{"rank": rank, "local_rank": local_rank, "device_count": n_dev, "device": torch.cuda.current_device()}]
@@ -286,6 +297,8 @@ def main():
         "dtype": "u32 (BabyBear Montgomery, 31-bit modular)",
         "data": "synthetic",
         "config": dict(job.config(), workload=job.workload_name(), hash=args.hash,
+                       step_pipelining="depth 1: step k+1's instances are dealt to the prover threads before step k's last proofs "
+                                       "finish; all K steps complete inside the timed region",
                        parallelism=("independent proofs, instance i -> rank i mod N; RCCL only scatters descriptors / gathers proof bytes"
                                     if args.workload != "cfg5" else "replicas only (one matrix per rank, no collective)")),
         "roofline": roof,

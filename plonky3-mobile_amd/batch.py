@@ -61,11 +61,12 @@ class _PendingGather:
 
 
 class ProofGatherer:
-    """Double-buffered staging for the per-step gather of proof bytes to rank 0.
+    """Staging for the per-step gather of proof bytes to rank 0: three slots used round-robin, so that step k + 1 can be
+    filling one while step k's gather is in flight and step k - 1's proofs are still being read on rank 0.
 
-    open(n_local, width) hands out a sink the prover threads call as sink(row, index, proof) the moment a proof is
-    serialised (the copy into the pinned buffer overlaps the other provers' GPU work); launch() enqueues ONE H2D copy
-    and the two gathers and returns at once.  On a GPU backend rank 0 also enqueues the copies of the received buffers
+    open(n_local, width) -> (sink, slot): the prover threads call sink(row, index, proof) the moment a proof is
+    serialised (the copy into the pinned buffer overlaps the other provers' GPU work); launch(slot) enqueues ONE H2D
+    copy and the two gathers and returns at once.  On a GPU backend rank 0 also enqueues the copies of the received buffers
     into pinned host memory and an event behind them, so wait() costs no device round trip on the critical path.
     `width` (bytes per proof slot) must be the same on every rank: proofs of one parameter set have one length, so
     the caller learns it from the first step (gather_proofs_async does the all_reduce) and passes it from then on."""
@@ -74,10 +75,10 @@ class ProofGatherer:
         self.n_total, self.device = n_total, str(device)
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.per = (n_total + self.world - 1) // self.world
-        self.slots, self.turn, self.cur = {}, 0, None
+        self.slots, self.turn = {}, 0
 
     def _slot(self, width):
-        self.turn ^= 1
+        self.turn = (self.turn + 1) % 3
         key = (width, self.turn)
         ent = self.slots.get(key)
         if ent is None:
@@ -102,7 +103,7 @@ class ProofGatherer:
     def open(self, n_local, width):
         if n_local > self.per:
             raise ValueError("%d local proofs for %d slots" % (n_local, self.per))
-        ent = self.cur = self._slot(width)
+        ent = self._slot(width)
         host, meta = ent["h"].numpy(), ent["hm"].numpy()
         meta[:] = -1
 
@@ -111,10 +112,9 @@ class ProofGatherer:
                 raise ValueError("proof of %d bytes does not fit the agreed slot of %d" % (len(proof), width))
             host[row, : len(proof)] = np.frombuffer(proof, dtype=np.uint8)
             meta[row] = (index, len(proof))
-        return sink
+        return sink, ent
 
-    def launch(self):
-        ent, self.cur = self.cur, None
+    def launch(self, ent):
         if self.device == "cpu":
             buf, meta = ent["h"], ent["hm"]
         else:
@@ -151,10 +151,10 @@ def gather_proofs_async(local, n_total, device="cpu", width=None):
     g = _GATHERERS.get((n_total, str(device)))
     if g is None:
         g = _GATHERERS[(n_total, str(device))] = ProofGatherer(n_total, device)
-    sink = g.open(len(local), width)
+    sink, slot = g.open(len(local), width)
     for k, (i, p) in enumerate(local):
         sink(k, i, p)
-    pend = g.launch()
+    pend = g.launch(slot)
     pend.width = width
     return pend
 

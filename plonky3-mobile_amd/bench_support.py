@@ -90,6 +90,7 @@ class FibAirJob:
         for w in self.workers:
             w.result()
         self.last = None
+        self._begun = []
 
     def close(self):
         for w in self.workers:
@@ -199,14 +200,14 @@ class FibAirJob:
             jobs.put(item)
         for w in self.workers:
             w.inbox.put(("prove", (jobs, sink)))
-        self._open = instances is not None
+        self._begun.append(instances is not None)  # steps may overlap: step_end() retires them in order
 
     def step_end(self):
         got = {}
         for w in self.workers:
             for i, pf in w.result():
                 got[i] = pf
-        if self._open:
+        if self._begun.pop(0):
             self.last = got
             return got
         res = [got[i] for i in range(self.batch)]
@@ -375,6 +376,12 @@ class WideCommitJob:
         self._lde()
         self.last_root = self._commit()
         return self.last_root
+
+    def step_begin(self, instances=None, sink=None):  # one matrix per step: nothing to overlap
+        self._res = self.step()
+
+    def step_end(self):
+        return self._res
 
     _time = FibAirJob._time
 

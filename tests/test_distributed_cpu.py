@@ -112,8 +112,9 @@ def _worker_pipelined(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    # bench.py's steady state: collectives in the order scatter(k+1), gather(k) on every rank; the proofs of step k
-    # are written into the staging rows by "prover" threads through the sink; fixed slot width; rank 0 reads views.
+    # bench.py's steady state: step k + 1 is issued (scatter, staging slot opened, "prover" threads writing through the
+    # sink) BEFORE step k retires (gather launched, gather k - 1 collected): collectives in the order scatter(k+1),
+    # gather(k) on every rank, three staging slots in rotation, fixed slot width, rank 0 reads views.
     n_total, width, results, pending = 7, 64, [], None
     g = batch.ProofGatherer(n_total, "cpu")
 
@@ -121,23 +122,31 @@ def _worker_pipelined(rank, world, port, q):
         inst = [(10 * step + i, 10 * step + i + 1) for i in range(n_total)] if rank == 0 else []
         return batch.scatter_descriptors(inst)
 
-    nxt = descriptors(0)
-    for step in range(6):
-        mine = nxt
-        put = g.open(len(mine), width)
+    def issue(step):
+        mine = descriptors(step)
+        put, slot = g.open(len(mine), width)
         ths = [threading.Thread(target=lambda r=r, i=i, a=a, b=b: put(r, i, b"S%d:%d:%d:%d" % (step, i, a, b) * (1 + i % 3)))
                for r, (i, a, b) in enumerate(mine)]
         [t.start() for t in ths]
-        if pending is not None:
-            res = pending.wait(copy=False)
-            results.append([bytes(x) for x in res] if res is not None else None)
-        nxt = descriptors(step + 1)
+        return ths, slot
+
+    def retire(ths, slot):
+        nonlocal pending
         [t.join() for t in ths]
-        pending = g.launch()
+        prev, pending = pending, g.launch(slot)
+        if prev is not None:
+            res = prev.wait(copy=False)
+            results.append([bytes(x) for x in res] if res is not None else None)
+
+    inflight = [issue(0)]
+    for step in range(1, 7):
+        inflight.append(issue(step))
+        retire(*inflight.pop(0))
+    retire(*inflight.pop(0))
     res = pending.wait(copy=False)
     results.append([bytes(x) for x in res] if res is not None else None)
     try:
-        g.open(1, width)(0, 0, b"x" * (width + 1))
+        g.open(1, width)[0](0, 0, b"x" * (width + 1))
         overflow = "accepted"
     except ValueError:
         overflow = "refused"
@@ -149,7 +158,7 @@ def _worker_pipelined(rank, world, port, q):
 
 def test_pipelined_gatherer_world2():
     """ProofGatherer as bench.py drives it: prefetched scatter, sink called from threads, fixed slot width, zero-copy
-    views on rank 0, six steps over the two staging slots; an oversized proof is refused, not truncated."""
+    views on rank 0, seven overlapping steps over the three staging slots; an oversized proof is refused, not truncated."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -162,7 +171,7 @@ def test_pipelined_gatherer_world2():
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     assert overflow == "refused"
-    assert len(results) == 6
+    assert len(results) == 7
     for step, allp in enumerate(results):
         assert allp == [b"S%d:%d:%d:%d" % (step, i, 10 * step + i, 10 * step + i + 1) * (1 + i % 3) for i in range(7)], step
 

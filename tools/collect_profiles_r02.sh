@@ -26,6 +26,7 @@ say "other workloads"
 python3 bench.py --workload cfg3 > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err
 python3 bench.py --workload cfg5 > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err
 python3 bench.py --hash keccak > $OUT/bench_keccak.json 2> $OUT/bench_keccak.err
+python3 bench.py --hash keccak --hiding > $OUT/bench_keccak_hiding.json 2> $OUT/bench_keccak_hiding.err
 say "2-rank rehearsal over gloo on one GPU (NOT RCCL)"
 P3HIP_BENCH_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 4 --warmup 1 --batch 8 --threads 4 > $OUT/bench_2rank_gloo_rehearsal.json 2> $OUT/bench_2rank_gloo.err
 say "hiding prover timing"

@@ -82,6 +82,29 @@ def test_concurrent_provers_on_threads(p3, oracle):
         assert out[i][0] == ref and out[i][1] == ref
 
 
+def test_bench_job_overlapping_steps(p3, oracle):
+    """bench.py's step pipeline: step k + 1 is dealt to the prover threads before step k retires; every step still
+    returns exactly its own proofs (bytes equal to the oracle's), in order, and the sink sees each proof once."""
+    from plonky3_mobile_amd import bench_support as bs
+    job = bs.FibAirJob(p3, 9, 1, batch=5, threads=3)
+    ofp = oracle.FriParams(*[getattr(job.params, k) for k in ("log_blowup", "log_final_poly_len", "num_queries", "proof_of_work_bits")])
+    try:
+        seen = []
+        job.step_begin()                                              # default instances (first + i)
+        job.step_begin([(7, 40), (3, 41), (9, 42)], lambda i, pf: seen.append((i, pf)))
+        job.step_begin([(0, 50)])
+        first = job.step_end()
+        second = job.step_end()
+        third = job.step_end()
+        assert first == [oracle.prove_fib_air(i, i + 1, 9, ofp) for i in range(5)]
+        assert second == {7: oracle.prove_fib_air(40, 41, 9, ofp), 3: oracle.prove_fib_air(41, 42, 9, ofp),
+                          9: oracle.prove_fib_air(42, 43, 9, ofp)}
+        assert sorted(seen) == sorted(second.items())
+        assert third == {0: oracle.prove_fib_air(50, 51, 9, ofp)}
+    finally:
+        job.close()
+
+
 def test_bad_parameters(p3, oracle):
     with pytest.raises(p3.P3HipError):
         p3.FibAirProver(0)

@@ -14,6 +14,17 @@
 
 namespace p3 {
 
+// First statement of every LATENCY-bound kernel (single-wave transcript steps, lane-cooperative tree levels, the small
+// FRI folds, query gathers): raise the wave's issue priority.  When several provers share the chip such a kernel's
+// few waves sit on SIMDs beside up to eight waves of another prover's hash layer, and with equal priority the arbiter
+// gives them an eighth of the issue slots: its dependent instruction chain then runs 2-3x slower (tree_levels_coop:
+// 20 us alone, 51 us under four provers) while the large kernel would not notice the difference.
+#ifndef P3_NO_SETPRIO
+#define P3_LATENCY_BOUND_KERNEL() __builtin_amdgcn_s_setprio(3)
+#else
+#define P3_LATENCY_BOUND_KERNEL() ((void)0)
+#endif
+
 enum Status : int {
     OK = 0,
     ERR_BAD_ARG = -1,   // null pointer / non power-of-two height / bad width

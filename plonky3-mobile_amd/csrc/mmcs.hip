@@ -99,6 +99,7 @@ __global__ void __launch_bounds__(256) compress_layer_kernel(const uint32_t* pre
 // levels inside one workgroup, current layer mirrored in LDS.  layers: consecutive layers in HBM,
 // layer with n digests followed by the one with n/2.
 __global__ void __launch_bounds__(256) tree_top_kernel(uint32_t* layer0, uint32_t n0) {
+    P3_LATENCY_BOUND_KERNEL();
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t tid = threadIdx.x;
     for (uint32_t i = tid; i < n0 * 8; i += blockDim.x) lds[i] = layer0[i];
@@ -198,6 +199,7 @@ __global__ void __launch_bounds__(256) compress_layer_f64_kernel(const uint32_t*
 // ---- lane-cooperative kernels for small layers (16 lanes per permutation, poseidon2_coop.hip.h) ----
 // next[i] = compress(prev[2i], prev[2i+1]); one 16-lane row per output digest.
 __global__ void __launch_bounds__(256) compress_coop_kernel(const uint32_t* prev, uint32_t* next, uint32_t n_out) {
+    P3_LATENCY_BOUND_KERNEL();
     const uint32_t lane16 = threadIdx.x & 15;
     const p2c::LaneConst lc = p2c::lane_constants(lane16);
     uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -208,6 +210,7 @@ __global__ void __launch_bounds__(256) compress_coop_kernel(const uint32_t* prev
 }
 // leaf digests of ONE matrix (any width): row r absorbed 8 words at a time by lanes 0..7 of its row of lanes.
 __global__ void __launch_bounds__(256) leaf_coop_kernel(const uint32_t* mat, uint32_t width, uint32_t n_rows, uint32_t* digests) {
+    P3_LATENCY_BOUND_KERNEL();
     const uint32_t lane16 = threadIdx.x & 15;
     const p2c::LaneConst lc = p2c::lane_constants(lane16);
     uint32_t r = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -226,6 +229,7 @@ __global__ void __launch_bounds__(256) leaf_coop_kernel(const uint32_t* mat, uin
 // level produces the root it is also written to `root_copy` (host-mapped) if given.
 __global__ void __launch_bounds__(1024) tree_levels_coop_kernel(uint32_t* layer_in, uint32_t n_in, uint32_t chunk, uint32_t levels,
                                                                 uint32_t* root_copy) {
+    P3_LATENCY_BOUND_KERNEL();
     __shared__ uint32_t lds[128 * 8];
     const uint32_t tid = threadIdx.x, lane16 = tid & 15, grp = tid >> 4;
     const p2c::LaneConst lc = p2c::lane_constants(lane16);
@@ -428,6 +432,7 @@ __global__ void __launch_bounds__(256) keccak_compress_kernel(const uint32_t* pr
 // layer0: consecutive layers in HBM (n_in digests, then n_in / 2, ...).
 __global__ void __launch_bounds__(1024) keccak_tree_levels_kernel(uint32_t* layer0, uint32_t n_in, uint32_t chunk, uint32_t levels,
                                                                   uint32_t* root_copy) {
+    P3_LATENCY_BOUND_KERNEL();
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t tid = threadIdx.x, blk = blockIdx.x;
     const uint4* src = reinterpret_cast<const uint4*>(layer0) + (size_t)blk * chunk * 2;
@@ -466,6 +471,7 @@ __global__ void __launch_bounds__(1024) keccak_tree_levels_kernel(uint32_t* laye
 // above, at several times its lane-instructions — so only layers of <= 2^12 digests come here (mmcs_commit).
 __global__ void __launch_bounds__(1024) keccak_tree_levels_coop_kernel(uint32_t* layer0, uint32_t n_in, uint32_t chunk, uint32_t levels,
                                                                        uint32_t* root_copy) {
+    P3_LATENCY_BOUND_KERNEL();
     __shared__ uint64_t lds[32 * 4];
     const uint32_t tid = threadIdx.x, blk = blockIdx.x, wv = tid >> 6, idx = kk::coop_index();
     if (tid < chunk * 4) lds[tid] = reinterpret_cast<const uint64_t*>(layer0)[(size_t)blk * chunk * 4 + tid];
@@ -517,6 +523,7 @@ struct OpenArgs {
     uint32_t log_max_height;
 };
 __global__ void open_gather_kernel(OpenArgs a, const uint32_t* layers, uint64_t index, uint32_t* out) {
+    P3_LATENCY_BOUND_KERNEL();
     // rows
     uint32_t off = 0;
     for (uint32_t m = 0; m < a.n_mats; m++) {

@@ -246,6 +246,7 @@ __global__ void __launch_bounds__(256) reduced_openings_kernel(ReducedArgs a) {
 __global__ void __launch_bounds__(256) fri_fold_kernel(TwoLevelTable inv_roots /* w_len^-e */, const uint32_t* in,
                                                        uint32_t* out, uint32_t half, uint32_t log_half,
                                                        const DevState* __restrict__ ds, uint32_t round, uint32_t one_half) {
+    if (gridDim.x <= 256u) P3_LATENCY_BOUND_KERNEL();
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= half) return;
     const Ext half_beta = ds->half_beta[round];
@@ -322,6 +323,7 @@ struct QTree {
 };
 __global__ void query_gather_kernel(const QTree* trees, uint32_t n_trees, const uint32_t* indices, uint32_t slot_words,
                                     uint32_t* out) {
+    P3_LATENCY_BOUND_KERNEL();
     const QTree t = trees[blockIdx.y];
     // masked: whatever the index buffer holds, the gather stays inside the tree
     uint64_t index = (indices[blockIdx.x] >> t.shift) & ((1ull << t.log_height) - 1ull);
@@ -353,6 +355,7 @@ struct TsArgs {
 
 // observe the instance, sample alpha: p3_uni_stark::prove up to the quotient computation
 __global__ void __launch_bounds__(64) ts_begin_kernel(TsArgs a, const uint32_t* trace, uint32_t n, uint32_t log_n) {
+    P3_LATENCY_BOUND_KERNEL();
     __shared__ KState ks;
     DevChal ch;
     ch.begin(a.kind, a.ds, &ks, true);
@@ -376,6 +379,7 @@ __global__ void __launch_bounds__(64) ts_begin_kernel(TsArgs a, const uint32_t* 
 }
 // observe the quotient commitment, sample zeta
 __global__ void __launch_bounds__(64) ts_zeta_kernel(TsArgs a, uint32_t g_n) {
+    P3_LATENCY_BOUND_KERNEL();
     __shared__ KState ks;
     DevChal ch;
     ch.begin(a.kind, a.ds, &ks, false);
@@ -394,6 +398,7 @@ __global__ void __launch_bounds__(64) ts_zeta_kernel(TsArgs a, uint32_t g_n) {
 constexpr int TS_OPEN_THREADS = 256;
 __global__ void __launch_bounds__(TS_OPEN_THREADS) ts_open_kernel(TsArgs a, const uint32_t* partials, uint32_t n_blocks,
                                                                   uint32_t log_n, uint32_t sn, uint32_t denom) {
+    P3_LATENCY_BOUND_KERNEL();
     __shared__ KState ks;
     __shared__ uint32_t red[TS_OPEN_THREADS / 32][32];
     __shared__ uint32_t tot[32];
@@ -457,6 +462,7 @@ __global__ void __launch_bounds__(TS_OPEN_THREADS) ts_open_kernel(TsArgs a, cons
 }
 // FRI commit phase, round r: observe the layer's commitment, sample beta
 __global__ void __launch_bounds__(64) ts_fri_round_kernel(TsArgs a, uint32_t round, uint32_t one_half) {
+    P3_LATENCY_BOUND_KERNEL();
     __shared__ KState ks;
     DevChal ch;
     ch.begin(a.kind, a.ds, &ks, false);
@@ -467,6 +473,7 @@ __global__ void __launch_bounds__(64) ts_fri_round_kernel(TsArgs a, uint32_t rou
 }
 // observe the final polynomial; set up the proof-of-work search
 __global__ void __launch_bounds__(64) ts_final_kernel(TsArgs a, uint32_t fpl, uint32_t pow_mask) {
+    P3_LATENCY_BOUND_KERNEL();
     __shared__ KState ks;
     DevChal ch;
     ch.begin(a.kind, a.ds, &ks, false);
@@ -501,6 +508,7 @@ __global__ void __launch_bounds__(64) ts_final_kernel(TsArgs a, uint32_t fpl, ui
 // check the witness, observe it, sample the query indices.  If the search range held no witness the transcript is
 // left untouched and the host continues the search (status = ST_GRIND_MISS).
 __global__ void __launch_bounds__(64) ts_queries_kernel(TsArgs a, uint32_t nq, uint32_t log_big, uint32_t pow_bits, uint32_t* qidx) {
+    P3_LATENCY_BOUND_KERNEL();
     __shared__ KState ks;
     const uint32_t found = a.ds->grind_result;
     if (found == 0xffffffffu) {

@@ -69,6 +69,7 @@ __device__ __forceinline__ void sponge_row(const RowSet& rs, uint64_t r, uint32_
 }
 
 __global__ void __launch_bounds__(256) leaf_hash_kernel(RowSet rs, uint64_t n_rows, uint32_t* digests) {
+    if (gridDim.x <= 512u) P3_LATENCY_BOUND_KERNEL();
     uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
     uint32_t s[16];
@@ -79,6 +80,7 @@ __global__ void __launch_bounds__(256) leaf_hash_kernel(RowSet rs, uint64_t n_ro
 // next[i] = compress(prev[2i], prev[2i+1]), optionally followed by compress(., sponge(row i of the set)).
 __global__ void __launch_bounds__(256) compress_layer_kernel(const uint32_t* prev, uint32_t* next, uint64_t n_out,
                                                              RowSet rs, uint32_t inject) {
+    if (gridDim.x <= 512u) P3_LATENCY_BOUND_KERNEL();
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_out) return;
     uint32_t s[16];
@@ -129,6 +131,7 @@ __global__ void __launch_bounds__(256) tree_top_kernel(uint32_t* layer0, uint32_
 // ---- fp64 variants of the two large one-state-per-lane kernels (poseidon2_f64.hip.h): same digests, ~7 % fewer
 // issue cycles.  Memory stays Montgomery u32; conversion happens in registers at load/store.
 __global__ void __launch_bounds__(256) leaf_hash_f64_kernel(const uint32_t* mat, uint32_t width, uint64_t n_rows, uint32_t* digests) {
+    if (gridDim.x <= 512u) P3_LATENCY_BOUND_KERNEL();
     uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
     double s[16];
@@ -154,6 +157,7 @@ __global__ void __launch_bounds__(256) leaf_hash_f64_kernel(const uint32_t* mat,
 // the same sponge over the CONCATENATED rows of several matrices of one height (the (matrix, salt) pairs of the hiding
 // MMCS, or any multi-matrix commitment): element k of the row comes from the matrix whose column range holds k
 __global__ void __launch_bounds__(256) leaf_hash_f64_rowset_kernel(RowSet rs, uint64_t n_rows, uint32_t* digests) {
+    if (gridDim.x <= 512u) P3_LATENCY_BOUND_KERNEL();
     uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
     double s[16];
@@ -181,6 +185,7 @@ __global__ void __launch_bounds__(256) leaf_hash_f64_rowset_kernel(RowSet rs, ui
     store_digest(digests + r * 8, d);
 }
 __global__ void __launch_bounds__(256) compress_layer_f64_kernel(const uint32_t* prev, uint32_t* next, uint64_t n_out) {
+    if (gridDim.x <= 512u) P3_LATENCY_BOUND_KERNEL();
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_out) return;
     uint32_t w[16];
@@ -394,6 +399,7 @@ __device__ __forceinline__ void store_digest64(uint32_t* p, const uint64_t (&st)
     q[1] = make_uint4((uint32_t)st[2], (uint32_t)(st[2] >> 32), (uint32_t)st[3], (uint32_t)(st[3] >> 32));
 }
 __global__ void __launch_bounds__(256) keccak_leaf_kernel(RowSet rs, uint64_t n_rows, uint32_t* digests) {
+    if (gridDim.x <= 512u) P3_LATENCY_BOUND_KERNEL();
     uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
     uint64_t st[25];
@@ -403,6 +409,7 @@ __global__ void __launch_bounds__(256) keccak_leaf_kernel(RowSet rs, uint64_t n_
 // CompressionFunctionFromHasher<U64Hash, 2, 4>: hash of the 8 lanes of the two child digests (one block)
 __global__ void __launch_bounds__(256) keccak_compress_kernel(const uint32_t* prev, uint32_t* next, uint64_t n_out,
                                                               RowSet rs, uint32_t inject) {
+    if (gridDim.x <= 512u) P3_LATENCY_BOUND_KERNEL();
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_out) return;
     uint32_t w[16];

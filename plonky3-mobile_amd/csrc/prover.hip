@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(256) reduced_openings_kernel(ReducedArgs a) {
 __global__ void __launch_bounds__(256) fri_fold_kernel(TwoLevelTable inv_roots /* w_len^-e */, const uint32_t* in,
                                                        uint32_t* out, uint32_t half, uint32_t log_half,
                                                        const DevState* __restrict__ ds, uint32_t round, uint32_t one_half) {
-    if (gridDim.x <= 256u) P3_LATENCY_BOUND_KERNEL();
+    if (gridDim.x <= 512u) P3_LATENCY_BOUND_KERNEL();
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= half) return;
     const Ext half_beta = ds->half_beta[round];

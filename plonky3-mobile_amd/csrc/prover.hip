@@ -12,6 +12,7 @@
 //   proof serialisation.  Wire format: u32 LE Montgomery words, u32 vector counts, Plonky3 struct order.
 // All of these passes are HBM- or integer-VALU-bound element-wise / reduction kernels: one lane per row,
 // 16-byte accesses, no MFMA.
+#include <chrono>
 #include <memory>
 #include <cstring>
 
@@ -705,6 +706,7 @@ int FibProver::prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof) {
     Context& cx = *cxp;
     if (cx.device != s.device)
         return fail(ERR_BAD_ARG, "fib prover: created on device " + std::to_string(s.device) + ", current device is " + std::to_string(cx.device));
+    const auto t_start = std::chrono::steady_clock::now();
     hipStream_t st = s.stream;
     const uint32_t log_n = s.log_n, log_big = s.log_big;
     const uint32_t n = 1u << log_n, big = 1u << log_big;
@@ -844,11 +846,14 @@ int FibProver::prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof) {
     };
     if ((rc = queries())) return rc;
     P3_HIP(hipEventRecord(s.ev[6], st));
+    const auto t_enq = std::chrono::steady_clock::now();
     P3_HIP(hipStreamSynchronize(st));  // the one synchronisation of a proof
     const uint32_t* hp = s.host_stage;
     static const bool trace = getenv("P3HIP_TRACE") != nullptr;
 #define TR(...) do { if (trace) { fprintf(stderr, __VA_ARGS__); fflush(stderr); } } while (0)
-    TR("prove: synced, status %u\n", hp[L.status]);
+    TR("prove: enqueued in %.0f us of host time, synced after another %.0f us, status %u\n",
+       std::chrono::duration<double, std::micro>(t_enq - t_start).count(),
+       std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enq).count(), hp[L.status]);
     if (hp[L.status] == ST_GRIND_MISS) {
         // continue the search range by range (each 4x the previous one), then redo the query phase
         uint32_t found = 0xffffffffu;

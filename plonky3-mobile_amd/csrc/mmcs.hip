@@ -390,7 +390,8 @@ __device__ __forceinline__ void keccak_sponge_row(const RowSet& rs, uint64_t r, 
                 st[k] = lo | (hi << 32);
             }
         }
-        kk::permute(st);
+        if (i + 17 >= n64) kk::permute_digest(st);  // the last block: only the digest words are read
+        else kk::permute(st);
     }
 }
 __device__ __forceinline__ void store_digest64(uint32_t* p, const uint64_t (&st)[25]) {
@@ -420,7 +421,7 @@ __global__ void __launch_bounds__(256) keccak_compress_kernel(const uint32_t* pr
     for (int k = 0; k < 8; k++) st[k] = (uint64_t)w[2 * k] | ((uint64_t)w[2 * k + 1] << 32);
 #pragma unroll
     for (int k = 8; k < 25; k++) st[k] = 0;
-    kk::permute(st);
+    kk::permute_digest(st);
     if (inject) {
         uint64_t h[25];
         keccak_sponge_row(rs, i, h);
@@ -428,7 +429,7 @@ __global__ void __launch_bounds__(256) keccak_compress_kernel(const uint32_t* pr
         for (int k = 0; k < 4; k++) st[4 + k] = h[k];
 #pragma unroll
         for (int k = 8; k < 25; k++) st[k] = 0;
-        kk::permute(st);
+        kk::permute_digest(st);
     }
     store_digest64(next + i * 8, st);
 }
@@ -457,7 +458,7 @@ __global__ void __launch_bounds__(1024) keccak_tree_levels_kernel(uint32_t* laye
             for (int i = 0; i < 8; i++) st[i] = p[i];
 #pragma unroll
             for (int i = 8; i < 25; i++) st[i] = 0;
-            kk::permute(st);
+            kk::permute_digest(st);
         }
         __syncthreads();
         if (act) {

@@ -301,7 +301,8 @@ __global__ void __launch_bounds__(256) grind_keccak_kernel(DevState* ds, uint32_
             }
             st[i] ^= lane;
         }
-        kk::permute(st);
+        if (blk + 1 == a.n_blocks) kk::permute_digest(st);  // only the digest words are read below
+        else kk::permute(st);
     }
     // digest bytes d[0..31] = lanes 0..3 little endian; pops come from d[31] downwards
     bool ok = false;

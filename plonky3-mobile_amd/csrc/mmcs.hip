@@ -150,8 +150,9 @@ __global__ void __launch_bounds__(256) leaf_hash_f64_kernel(const uint32_t* mat,
         }
     }
     uint32_t d[8];
+    const p2f::MagicRegs smk = p2f::magic_regs();
 #pragma unroll
-    for (int i = 0; i < 8; i++) d[i] = p2f::store_elem(s[i]);
+    for (int i = 0; i < 8; i++) d[i] = p2f::store_elem(s[i], smk);
     store_digest(digests + r * 8, d);
 }
 // the same sponge over the CONCATENATED rows of several matrices of one height (the (matrix, salt) pairs of the hiding
@@ -180,8 +181,9 @@ __global__ void __launch_bounds__(256) leaf_hash_f64_rowset_kernel(RowSet rs, ui
         }
     }
     uint32_t d[8];
+    const p2f::MagicRegs smk = p2f::magic_regs();
 #pragma unroll
-    for (int i = 0; i < 8; i++) d[i] = p2f::store_elem(s[i]);
+    for (int i = 0; i < 8; i++) d[i] = p2f::store_elem(s[i], smk);
     store_digest(digests + r * 8, d);
 }
 __global__ void __launch_bounds__(256) compress_layer_f64_kernel(const uint32_t* prev, uint32_t* next, uint64_t n_out) {
@@ -196,8 +198,9 @@ __global__ void __launch_bounds__(256) compress_layer_f64_kernel(const uint32_t*
     for (int k = 0; k < 16; k++) s[k] = p2f::load_elem(w[k]);
     p2f::permute(s);
     uint32_t d[8];
+    const p2f::MagicRegs smk = p2f::magic_regs();
 #pragma unroll
-    for (int k = 0; k < 8; k++) d[k] = p2f::store_elem(s[k]);
+    for (int k = 0; k < 8; k++) d[k] = p2f::store_elem(s[k], smk);
     store_digest(next + i * 8, d);
 }
 

@@ -78,6 +78,8 @@ _SIGS = {
     "p3hip_fib_batch_create_hash": (C.c_int, [C.c_int, C.c_uint, C.c_void_p, C.c_uint, C.POINTER(C.c_void_p)]),
     "p3hip_fib_batch_prove": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                         C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]),
+    "p3hip_fib_batch_submit": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "p3hip_fib_batch_collect": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]),
     "p3hip_fib_batch_destroy": (None, [C.c_void_p]),
     "p3hip_verify_fib_air": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint, C.c_void_p]),
     "p3hip_mmcs_commit": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),

@@ -7,6 +7,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <deque>
 #include <thread>
 #include <cctype>
 #include <cstdio>
@@ -631,15 +632,24 @@ struct p3hip_fib_batch {
     std::vector<std::thread> workers;
     std::mutex mu;
     std::condition_variable cv_work, cv_done;
-    // current job
-    uint64_t generation = 0;
+    // Batches in submit order.  A worker takes the next unproved instance of the OLDEST batch that still has one, so a
+    // prover that has finished its share of one batch starts on the next at once (no join between batches).
+    struct Job {
+        uint64_t ticket = 0;
+        std::vector<uint64_t> a, b;
+        size_t next = 0, done = 0;
+        std::vector<std::vector<uint8_t>> proofs;
+        int first_error = 0;
+        std::string error_text;
+    };
+    std::deque<std::shared_ptr<Job>> jobs;   // submitted, not yet collected
+    std::shared_ptr<Job> collected;          // the proofs handed out by the last collect stay alive until the next one
+    uint64_t next_ticket = 1;
     bool stop = false;
-    size_t n = 0, next = 0, done = 0, ready = 0;
-    const uint64_t* a = nullptr;
-    const uint64_t* b = nullptr;
-    std::vector<std::vector<uint8_t>> proofs;
-    int first_error = 0;
+    size_t ready = 0;
+    int first_error = 0;  // of the workers' start-up
     std::string error_text;
+    static constexpr size_t MAX_INFLIGHT = 8;
 
     void worker_main() {
         {
@@ -655,6 +665,11 @@ struct p3hip_fib_batch {
         catch (const std::exception& e) { return fail(ERR_INTERNAL, std::string("exception: ") + e.what()); }
         catch (...) { return fail(ERR_INTERNAL, "unknown exception"); }
     }
+    std::shared_ptr<Job> pick(size_t* index) {  // under mu
+        for (auto& j : jobs)
+            if (j->next < j->a.size()) { *index = j->next++; return j; }
+        return nullptr;
+    }
     void worker_loop(FibProver& prover) {
         int rc = no_throw([&]() -> int {
             if (hipSetDevice(device) != hipSuccess) return fail(ERR_HIP, "hipSetDevice failed in a batch worker");
@@ -664,30 +679,32 @@ struct p3hip_fib_batch {
             if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return fail(ERR_HIP, "hipStreamCreateWithFlags failed");
             return prover.init(log_n, fp, st, true, hash);
         });
+        std::string start_text;
+        if (rc != OK) take_error(&start_text);
         {
             std::unique_lock<std::mutex> lk(mu);
-            if (rc != OK && first_error == 0) { first_error = rc; std::string t; take_error(&t); error_text = t; }
+            if (rc != OK && first_error == 0) { first_error = rc; error_text = start_text; }
             ready++;
             cv_done.notify_all();
         }
-        uint64_t seen = 0;
         for (;;) {
-            size_t i;
+            std::shared_ptr<Job> job;
+            size_t i = 0;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv_work.wait(lk, [&] { return stop || (generation != seen && next < n) ; });
-                if (stop) return;
-                if (next >= n) { seen = generation; continue; }
-                i = next++;
+                cv_work.wait(lk, [&] { return stop || (job = pick(&i)) != nullptr; });
+                if (!job) return;  // stop
             }
             int prc = rc;
-            if (prc == OK) prc = no_throw([&]() -> int { return prover.prove(a[i], b[i], &proofs[i]); });
+            std::string text = start_text;
+            if (prc == OK) {
+                prc = no_throw([&]() -> int { return prover.prove(job->a[i], job->b[i], &job->proofs[i]); });
+                if (prc != OK) take_error(&text);
+            }
             {
                 std::unique_lock<std::mutex> lk(mu);
-                if (prc != OK && first_error == 0) { first_error = prc; std::string t; take_error(&t); error_text = t; }
-                done++;
-                if (next >= n) seen = generation;
-                if (done == n) cv_done.notify_all();
+                if (prc != OK && job->first_error == 0) { job->first_error = prc; job->error_text = text; }
+                if (++job->done == job->a.size()) cv_done.notify_all();
             }
         }
     }
@@ -725,23 +742,52 @@ int p3hip_fib_batch_create_hash(int hash, unsigned log_n, const p3hip_fri_params
     });
 }
 
-int p3hip_fib_batch_prove(p3hip_fib_batch_t* bt, size_t n, const uint64_t* a, const uint64_t* b, const uint8_t** proofs_out,
-                          size_t* lens_out) {
+int p3hip_fib_batch_submit(p3hip_fib_batch_t* bt, size_t n, const uint64_t* a, const uint64_t* b, uint64_t* ticket_out) {
     return guarded([&]() -> int {
-        if (!bt || (n && (!a || !b || !proofs_out || !lens_out))) return fail(ERR_BAD_ARG, "fib_batch_prove: null argument");
-        if (!n) return OK;
-        {
-            std::unique_lock<std::mutex> lk(bt->mu);
-            if (bt->proofs.size() < n) bt->proofs.resize(n);
-            bt->n = n; bt->next = 0; bt->done = 0; bt->a = a; bt->b = b; bt->first_error = 0;
-            bt->generation++;
-            bt->cv_work.notify_all();
-            bt->cv_done.wait(lk, [&] { return bt->done == n; });
-            if (bt->first_error) return fail(bt->first_error, bt->error_text);
-        }
-        for (size_t i = 0; i < n; i++) { proofs_out[i] = bt->proofs[i].data(); lens_out[i] = bt->proofs[i].size(); }
+        if (!bt || !ticket_out || (n && (!a || !b))) return fail(ERR_BAD_ARG, "fib_batch_submit: null argument");
+        auto job = std::make_shared<p3hip_fib_batch::Job>();
+        job->a.assign(a, a + n);
+        job->b.assign(b, b + n);
+        job->proofs.resize(n);
+        std::unique_lock<std::mutex> lk(bt->mu);
+        if (bt->jobs.size() >= p3hip_fib_batch::MAX_INFLIGHT)
+            return fail(ERR_BAD_ARG, "fib_batch_submit: too many batches in flight (collect one first)");
+        job->ticket = bt->next_ticket++;
+        *ticket_out = job->ticket;
+        bt->jobs.push_back(job);
+        bt->cv_work.notify_all();
         return OK;
     });
+}
+
+int p3hip_fib_batch_collect(p3hip_fib_batch_t* bt, uint64_t ticket, const uint8_t** proofs_out, size_t* lens_out) {
+    return guarded([&]() -> int {
+        if (!bt) return fail(ERR_BAD_ARG, "fib_batch_collect: null argument");
+        std::shared_ptr<p3hip_fib_batch::Job> job;
+        {
+            std::unique_lock<std::mutex> lk(bt->mu);
+            auto it = std::find_if(bt->jobs.begin(), bt->jobs.end(), [&](const std::shared_ptr<p3hip_fib_batch::Job>& j) { return j->ticket == ticket; });
+            if (it == bt->jobs.end()) return fail(ERR_BAD_ARG, "fib_batch_collect: unknown ticket");
+            job = *it;
+            if (job->a.size() && (!proofs_out || !lens_out)) return fail(ERR_BAD_ARG, "fib_batch_collect: null argument");
+            bt->cv_done.wait(lk, [&] { return job->done == job->a.size(); });
+            bt->jobs.erase(std::find(bt->jobs.begin(), bt->jobs.end(), job));
+            bt->collected = job;  // keeps the proof bytes alive until the next collect / prove / destroy
+        }
+        if (job->first_error) return fail(job->first_error, job->error_text);
+        for (size_t i = 0; i < job->a.size(); i++) { proofs_out[i] = job->proofs[i].data(); lens_out[i] = job->proofs[i].size(); }
+        return OK;
+    });
+}
+
+int p3hip_fib_batch_prove(p3hip_fib_batch_t* bt, size_t n, const uint64_t* a, const uint64_t* b, const uint8_t** proofs_out,
+                          size_t* lens_out) {
+    if (!bt || (n && (!a || !b || !proofs_out || !lens_out))) return fail(ERR_BAD_ARG, "fib_batch_prove: null argument");
+    if (!n) return OK;
+    uint64_t ticket = 0;
+    int rc = p3hip_fib_batch_submit(bt, n, a, b, &ticket);
+    if (rc) return rc;
+    return p3hip_fib_batch_collect(bt, ticket, proofs_out, lens_out);
 }
 
 void p3hip_fib_batch_destroy(p3hip_fib_batch_t* bt) {

@@ -279,6 +279,23 @@ class FibAirBatchProver:
         _lib.check(_lib.lib().p3hip_fib_batch_prove(self._h, n, a, b, ptrs, lens))
         return [C.string_at(ptrs[i], lens[i]) for i in range(n)]
 
+    def submit(self, instances):
+        """Queues a batch behind the ones already submitted and returns a ticket at once (at most 8 in flight)."""
+        n = len(instances)
+        a = (C.c_uint64 * n)(*[i[0] for i in instances])
+        b = (C.c_uint64 * n)(*[i[1] for i in instances])
+        ticket = C.c_uint64()
+        _lib.check(_lib.lib().p3hip_fib_batch_submit(self._h, n, a, b, C.byref(ticket)))
+        return (ticket.value, n)
+
+    def collect(self, ticket):
+        """Waits for a submitted batch; returns its proofs in instance order."""
+        t, n = ticket
+        ptrs = (C.POINTER(C.c_uint8) * max(n, 1))()
+        lens = (C.c_size_t * max(n, 1))()
+        _lib.check(_lib.lib().p3hip_fib_batch_collect(self._h, t, ptrs, lens))
+        return [C.string_at(ptrs[i], lens[i]) for i in range(n)]
+
     def close(self):
         if self._h:
             _lib.lib().p3hip_fib_batch_destroy(self._h)

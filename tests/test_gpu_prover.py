@@ -105,6 +105,29 @@ def test_bench_job_overlapping_steps(p3, oracle):
         job.close()
 
 
+def test_batch_pool_submit_collect(p3, oracle):
+    """The pool's pipelined form: three batches submitted before the first is collected, collected out of order; every
+    proof equals the oracle's; a ninth batch in flight is refused; an unknown ticket is an error."""
+    gfp, ofp = _fp(p3, oracle, 1, 0, 12, 5)
+    pool = p3.FibAirBatchProver(9, n_provers=3, params=gfp)
+    try:
+        batches = [[(10 * k + i, 10 * k + i + 1) for i in range(4 + k)] for k in range(3)]
+        tickets = [pool.submit(bt) for bt in batches]
+        for k in (1, 0, 2):
+            assert pool.collect(tickets[k]) == [oracle.prove_fib_air(a, b, 9, ofp) for a, b in batches[k]]
+        assert pool.prove(batches[0][:2]) == [oracle.prove_fib_air(a, b, 9, ofp) for a, b in batches[0][:2]]
+        with pytest.raises(p3.P3HipError):
+            pool.collect(tickets[0])  # already collected
+        more = [pool.submit([(0, 1)]) for _ in range(8)]
+        with pytest.raises(p3.P3HipError):
+            pool.submit([(0, 1)])
+        for t in more:
+            assert pool.collect(t) == [oracle.prove_fib_air(0, 1, 9, ofp)]
+        assert pool.collect(pool.submit([])) == []
+    finally:
+        pool.close()
+
+
 def test_bad_parameters(p3, oracle):
     with pytest.raises(p3.P3HipError):
         p3.FibAirProver(0)

@@ -238,6 +238,10 @@ int p3hip_fib_batch_create(unsigned log_n, const p3hip_fri_params_t *params, uns
 /* the pool under either hash configuration (P3HIP_HASH_POSEIDON2 / P3HIP_HASH_KECCAK) */
 int p3hip_fib_batch_create_hash(int hash, unsigned log_n, const p3hip_fri_params_t *params, unsigned n_provers,
                                 p3hip_fib_batch_t **out);
+/* the pool in the reference's hiding configuration (fib_air.rs:40-65): every prover's SmallRng streams start from `seed`
+ * for every proof, as a freshly built config would */
+int p3hip_fib_batch_create_hiding(int hash, unsigned log_n, const p3hip_fri_params_t *params, uint64_t seed, unsigned n_provers,
+                                  p3hip_fib_batch_t **out);
 int p3hip_fib_batch_prove(p3hip_fib_batch_t *batch, size_t n, const uint64_t *a, const uint64_t *b,
                           const uint8_t **proofs_out, size_t *lens_out);
 /* The same in two halves, for callers that keep the pool busy: submit copies the instance list, queues the batch behind

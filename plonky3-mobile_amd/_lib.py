@@ -76,6 +76,7 @@ _SIGS = {
                                                C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
     "p3hip_fib_batch_create": (C.c_int, [C.c_uint, C.c_void_p, C.c_uint, C.POINTER(C.c_void_p)]),
     "p3hip_fib_batch_create_hash": (C.c_int, [C.c_int, C.c_uint, C.c_void_p, C.c_uint, C.POINTER(C.c_void_p)]),
+    "p3hip_fib_batch_create_hiding": (C.c_int, [C.c_int, C.c_uint, C.c_void_p, C.c_uint64, C.c_uint, C.POINTER(C.c_void_p)]),
     "p3hip_fib_batch_prove": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                         C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]),
     "p3hip_fib_batch_submit": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

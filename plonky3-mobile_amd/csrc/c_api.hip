@@ -651,10 +651,15 @@ struct p3hip_fib_batch {
     std::string error_text;
     static constexpr size_t MAX_INFLIGHT = 8;
 
+    bool hiding = false;  // provers of the reference's hiding configuration (every one seeded with `seed`, as a fresh
+    uint64_t seed = 1;    // config per proof would be: fib_air.rs:50,65)
     void worker_main() {
-        {
+        if (hiding) {
+            FibHidingProver prover;
+            worker_loop(prover, [&](hipStream_t st) { return prover.init(log_n, fp, st, true, hash, seed); });
+        } else {
             FibProver prover;
-            worker_loop(prover);
+            worker_loop(prover, [&](hipStream_t st) { return prover.init(log_n, fp, st, true, hash); });
         }  // the prover (arena, stream) is gone before the thread's tables and scratch are freed
         release_thread_contexts();
     }
@@ -670,14 +675,15 @@ struct p3hip_fib_batch {
             if (j->next < j->a.size()) { *index = j->next++; return j; }
         return nullptr;
     }
-    void worker_loop(FibProver& prover) {
+    template <class Prover, class Init>
+    void worker_loop(Prover& prover, Init&& init) {
         int rc = no_throw([&]() -> int {
             if (hipSetDevice(device) != hipSuccess) return fail(ERR_HIP, "hipSetDevice failed in a batch worker");
             int r = get_context_status();
             if (r) return r;
             hipStream_t st = nullptr;
             if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return fail(ERR_HIP, "hipStreamCreateWithFlags failed");
-            return prover.init(log_n, fp, st, true, hash);
+            return init(st);
         });
         std::string start_text;
         if (rc != OK) take_error(&start_text);
@@ -716,14 +722,25 @@ extern "C" {
 int p3hip_fib_batch_create(unsigned log_n, const p3hip_fri_params_t* params, unsigned n_provers, p3hip_fib_batch_t** out) {
     return p3hip_fib_batch_create_hash(HASH_POSEIDON2, log_n, params, n_provers, out);
 }
+static int fib_batch_create(int hash, unsigned log_n, const p3hip_fri_params_t* params, unsigned n_provers, bool hiding,
+                            uint64_t seed, p3hip_fib_batch_t** out);
 int p3hip_fib_batch_create_hash(int hash, unsigned log_n, const p3hip_fri_params_t* params, unsigned n_provers,
                                 p3hip_fib_batch_t** out) {
+    return fib_batch_create(hash, log_n, params, n_provers, false, 1, out);
+}
+int p3hip_fib_batch_create_hiding(int hash, unsigned log_n, const p3hip_fri_params_t* params, uint64_t seed, unsigned n_provers,
+                                  p3hip_fib_batch_t** out) {
+    return fib_batch_create(hash, log_n, params, n_provers, true, seed, out);
+}
+static int fib_batch_create(int hash, unsigned log_n, const p3hip_fri_params_t* params, unsigned n_provers, bool hiding,
+                            uint64_t seed, p3hip_fib_batch_t** out) {
     return guarded([&]() -> int {
         if (!params || !out || n_provers == 0 || n_provers > 64) return fail(ERR_BAD_ARG, "fib_batch_create: bad argument");
         if (hash != HASH_POSEIDON2 && hash != HASH_KECCAK) return fail(ERR_BAD_ARG, "fib_batch_create: unknown hash configuration");
         std::unique_ptr<p3hip_fib_batch> bt(new p3hip_fib_batch());
         bt->log_n = log_n;
         bt->hash = hash;
+        bt->hiding = hiding; bt->seed = seed;
         P3_HIP(hipGetDevice(&bt->device));
         bt->fp = FriParams{params->log_blowup, params->log_final_poly_len, params->num_queries, params->proof_of_work_bits};
         for (unsigned t = 0; t < n_provers; t++) bt->workers.emplace_back([p = bt.get()] { p->worker_main(); });

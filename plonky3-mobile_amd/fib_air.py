@@ -262,12 +262,16 @@ class FibAirBatchProver:
     """A pool of provers inside libp3hip (one host thread + stream + HBM arena each) proving batches of
     independent instances — BASELINE configs[3] on one GPU; across GPUs see batch.py."""
 
-    def __init__(self, log_n, n_provers=8, params=None, hash="poseidon2"):
+    def __init__(self, log_n, n_provers=8, params=None, hash="poseidon2", hiding=False, seed=1):
         self.params = params or FriParameters()
         self.hash = hash
         self._h = C.c_void_p()
-        _lib.check(_lib.lib().p3hip_fib_batch_create_hash(_hash_kind(hash), log_n, C.cast(self.params._c(), C.c_void_p),
-                                                          n_provers, C.byref(self._h)))
+        if hiding:
+            _lib.check(_lib.lib().p3hip_fib_batch_create_hiding(_hash_kind(hash), log_n, C.cast(self.params._c(), C.c_void_p),
+                                                                seed, n_provers, C.byref(self._h)))
+        else:
+            _lib.check(_lib.lib().p3hip_fib_batch_create_hash(_hash_kind(hash), log_n, C.cast(self.params._c(), C.c_void_p),
+                                                              n_provers, C.byref(self._h)))
 
     def prove(self, instances):
         """instances: list of (a, b).  Returns the list of proof bytes in the same order."""

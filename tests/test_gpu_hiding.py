@@ -85,6 +85,21 @@ def test_hiding_one_fill_per_stream_equals_piecewise_fills(p3, oracle, monkeypat
     whole.close(), pieces.close()
 
 
+def test_hiding_batch_pool(p3, oracle):
+    """The prover pool in the reference's hiding configuration: every proof equals the oracle's (the streams restart from
+    the seed for every proof), through prove and through submit / collect."""
+    gfp, ofp = _fp(p3, oracle, 1, 0, 8, 4)
+    pool = p3.FibAirBatchProver(7, n_provers=3, params=gfp, hash="keccak", hiding=True, seed=1)
+    try:
+        inst = [(i, i + 1) for i in range(7)]
+        ref = [oracle.prove_fib_air_hiding(a, b, 7, ofp, hash=oracle.HASH_KECCAK, seed=1) for a, b in inst]
+        assert pool.prove(inst) == ref
+        t1, t2 = pool.submit(inst[:3]), pool.submit(inst[3:])
+        assert pool.collect(t2) == ref[3:] and pool.collect(t1) == ref[:3]
+    finally:
+        pool.close()
+
+
 def test_hiding_headline_size_verifies(p3, oracle):
     """2^18-row trace (randomized to 2^19, LDE 2^20), benchmark FRI parameters: the oracle's verifier accepts."""
     gfp, ofp = _fp(p3, oracle, 1, 0, 100, 16)

@@ -617,10 +617,12 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
         if (len == 1) break;
     }
     // Layers with fewer than COOP_MAX permutations cannot fill the chip with one state per lane: they run the
-    // 16-lanes-per-state kernels (latency ~6x lower); the last <= 1024 digests finish inside one workgroup.
-    // P3HIP_COOP_MAX_LOG: 15 minimises a single tree's latency; lower values spend fewer lane-instructions (the
-    // 16-lane form costs ~3.4x the VALU work of a one-state-per-lane permutation) when other work fills the chip
-    static const uint64_t COOP_MAX = [] { const char* e = getenv("P3HIP_COOP_MAX_LOG"); int v = e ? atoi(e) : 15; return (uint64_t)1 << (v < 7 ? 7 : (v > 15 ? 15 : v)); }();
+    // 16-lanes-per-state kernels (latency ~3x lower: ~3 us a level against ~8); the last digests finish inside one workgroup.
+    // P3HIP_COOP_MAX_LOG: 15 minimises a single tree's latency (a 2^20 proof: 3.3 ms against 3.6), but the 16-lane form
+    // costs ~3.4x the VALU work of a one-state-per-lane permutation, and since the small kernels run at raised wave
+    // priority (common.h) their latency no longer stretches under load: with four provers 12 is worth +5 %
+    // (557 -> 587 proofs/s; 10..12 within noise), so 12 is the default.
+    static const uint64_t COOP_MAX = [] { const char* e = getenv("P3HIP_COOP_MAX_LOG"); int v = e ? atoi(e) : 12; return (uint64_t)1 << (v < 7 ? 7 : (v > 15 ? 15 : v)); }();
     // digests per workgroup of the 16-lane cooperative Poseidon2 levels kernel: 2^5 = four waves, five levels per launch (2^7, sixteen
     // waves on one CU and seven levels, measured 1.5 % slower at four provers)
     static const uint32_t COOP_CHUNK_LOG = [] { const char* e = getenv("P3HIP_COOP_CHUNK_LOG"); int v = e ? atoi(e) : 5; return (uint32_t)(v < 3 ? 3 : (v > 7 ? 7 : v)); }();

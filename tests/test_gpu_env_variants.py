@@ -1,0 +1,28 @@
+"""The kernel-path switches (environment variables read once per process) select code that the default configuration no
+longer reaches — e.g. the 16-lane cooperative Poseidon2 for layers of 2^12..2^15 digests, the one-state-per-lane Keccak
+levels everywhere, large cooperative chunks.  Each variant runs tests/variant_check.py in a child process: trees layer by
+layer and proofs byte for byte against the oracle."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+VARIANTS = [
+    {"P3HIP_COOP_MAX_LOG": "15", "P3HIP_COOP_CHUNK_LOG": "7"},          # round-1 shape: cooperative below 2^15, 128-digest chunks
+    {"P3HIP_COOP_MAX_LOG": "8", "P3HIP_COOP_CHUNK_LOG": "3"},
+    {"P3HIP_KECCAK_COOP_MAX_LOG": "0", "P3HIP_KECCAK_LANE_CHUNK_LOG": "11"},  # no cooperative Keccak, 2048-digest workgroups
+    {"P3HIP_KECCAK_COOP_MAX_LOG": "15", "P3HIP_KECCAK_COOP_CHUNK_LOG": "5"},
+    {"P3HIP_NTT_NARROW_COSSPLIT": "0", "P3HIP_NTT_FUSED": "0", "P3HIP_HIDING_PIECEWISE": "1"},
+]
+
+
+@pytest.mark.parametrize("env", VARIANTS, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_switch_variant_matches_oracle(env):
+    child_env = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "variant_check.py")], env=child_env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "variant ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

@@ -102,9 +102,9 @@ __device__ __forceinline__ void permute_digest(uint64_t (&a)[25]) {
 // DPP row shift inside a 16-lane row — the wrap-around x = 4 -> 0 is a second shift restricted to half the banks, and
 // the zero padding makes the two shifted copies simply XOR together; the column parity is one row_ror:8 plus the
 // gfx950 v_permlane32_swap / v_permlane16_swap pair; rho is a per-lane v_alignbit pair; only pi crosses lanes
-// arbitrarily (two ds_bpermute).  About 55 wave-instructions and ONE LDS round trip per round (the first version:
-// shuffles for everything, 18 ds_bpermute in five dependent stages) — a permutation costs ~4 us instead of ~9, against
-// ~13 us for one lane holding all 25 words.  Every lane of the wave must call it.  Not inlined: one copy per kernel.
+// arbitrarily (two ds_bpermute).  68 wave-instructions and ONE LDS round trip per round (the first version:
+// shuffles for everything, 18 ds_bpermute in five dependent stages) — a permutation costs ~5 us instead of ~9, the
+// same ~9 us as one lane holding all 25 words (but a lane-instruction cost ~13x higher: small layers only).  Every lane of the wave must call it.  Not inlined: one copy per kernel.
 __device__ __forceinline__ uint32_t coop_index() {  // which state word this lane holds; 25 = padding lane
     const uint32_t lane = threadIdx.x & 63u, x = lane & 7u, y = lane >> 3;
     return (x < 5u && y < 5u) ? x + 5u * y : 25u;

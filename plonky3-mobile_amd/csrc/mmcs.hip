@@ -436,10 +436,10 @@ __global__ void __launch_bounds__(256) keccak_compress_kernel(const uint32_t* pr
     }
     store_digest64(next + i * 8, st);
 }
-// Several levels of a Keccak tree per launch: each workgroup reduces a chunk of `chunk` <= 2048 consecutive digests of
-// the current layer by `levels` levels inside LDS and writes every intermediate layer to HBM.  A level costs one
-// permutation latency either way (~13 us: the 64-bit lanes have no 16-lane cooperative form), but up to eleven
-// launches become one — the small layers of the ~22 trees of a proof were ~350 of its ~450 launches.
+// Several levels of a Keccak tree per launch, one state per lane: each workgroup reduces a chunk of `chunk` (128 by
+// default: one wave) consecutive digests of the current layer by `levels` levels inside LDS and writes every intermediate
+// layer to HBM.  A level costs one permutation's issue time (~9 us); the layers of 2^13..2^15 digests come here, the
+// smaller ones go to the lane-cooperative kernel below (mmcs_commit).
 // layer0: consecutive layers in HBM (n_in digests, then n_in / 2, ...).
 __global__ void __launch_bounds__(1024) keccak_tree_levels_kernel(uint32_t* layer0, uint32_t n_in, uint32_t chunk, uint32_t levels,
                                                                   uint32_t* root_copy) {
@@ -478,7 +478,7 @@ __global__ void __launch_bounds__(1024) keccak_tree_levels_kernel(uint32_t* laye
 }
 // The last levels of a Keccak tree with the lane-cooperative permutation (kk::f_coop, one compression per WAVE): a
 // workgroup of up to 16 waves holds a chunk of <= 32 consecutive digests in LDS and reduces it by up to five levels,
-// every intermediate layer written to HBM.  A level costs ~4 us instead of the ~13 us of the one-state-per-lane kernel
+// every intermediate layer written to HBM.  A level costs ~5 us instead of the ~9 us of the one-state-per-lane kernel
 // above, at several times its lane-instructions — so only layers of <= 2^12 digests come here (mmcs_commit).
 __global__ void __launch_bounds__(1024) keccak_tree_levels_coop_kernel(uint32_t* layer0, uint32_t n_in, uint32_t chunk, uint32_t levels,
                                                                        uint32_t* root_copy) {
@@ -627,7 +627,7 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
     // waves on one CU and seven levels, measured 1.5 % slower at four provers)
     static const uint32_t COOP_CHUNK_LOG = [] { const char* e = getenv("P3HIP_COOP_CHUNK_LOG"); int v = e ? atoi(e) : 5; return (uint32_t)(v < 3 ? 3 : (v > 7 ? 7 : v)); }();
     static const uint64_t KCOOP_IN = [] { const char* e = getenv("P3HIP_KECCAK_COOP_MAX_LOG"); int v = e ? atoi(e) : 12; return v <= 0 ? (uint64_t)0 : (uint64_t)1 << (v > 15 ? 15 : v); }();
-    // one-state-per-lane levels kernel: digests per workgroup.  A level costs one permutation's issue time (~13 us) per
+    // one-state-per-lane levels kernel: digests per workgroup.  A level costs one permutation's issue time (~9 us) per
     // wave a SIMD holds, so ONE wave per workgroup (128 digests) spreads a layer of <= 2^15 digests over the whole chip;
     // 2048 (sixteen waves on one CU) was 25 us per level
     static const uint64_t KLANE_CHUNK = [] { const char* e = getenv("P3HIP_KECCAK_LANE_CHUNK_LOG"); int v = e ? atoi(e) : 7; return (uint64_t)1 << (v < 7 ? 7 : (v > 11 ? 11 : v)); }();

@@ -183,6 +183,14 @@ int p3hip_fib_prover_create(unsigned log_n, const p3hip_fri_params_t *params, vo
  * Wire format: DESIGN.md "proof bytes". */
 int p3hip_fib_prover_prove(p3hip_fib_prover_t *prover, uint64_t a, uint64_t b, const uint8_t **proof_out,
                            size_t *proof_len);
+/* The same in two halves, to keep the prover's stream busy across proofs: enqueue returns as soon as the proof's launches
+ * are queued (nothing is waited for), finish waits for the OLDEST enqueued proof and returns its bytes (valid until the next
+ * prove / finish / destroy).  At most two proofs may be in flight; the second one's kernels queue behind the first on the
+ * prover's stream (the arena is reused in stream order, the results land in two pinned buffers), so the host's turnaround
+ * between proofs — wake-up, serialisation, the next enqueue: 0.2-0.3 ms at 2^20 — no longer leaves the stream empty.
+ * Not available for the hiding prover. */
+int p3hip_fib_prover_enqueue(p3hip_fib_prover_t *prover, uint64_t a, uint64_t b);
+int p3hip_fib_prover_finish(p3hip_fib_prover_t *prover, const uint8_t **proof_out, size_t *proof_len);
 /* host wall-clock per stage [trace commit, quotient commit, open, FRI commit phase, grind, queries] in ms,
  * accumulated over *proofs proofs */
 int p3hip_fib_prover_stage_times(p3hip_fib_prover_t *prover, double out_ms[6], uint64_t *proofs, int reset);

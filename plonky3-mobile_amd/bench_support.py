@@ -22,6 +22,7 @@ class _Worker(threading.Thread):
     def __init__(self, device, log_height, params, stagger_s=0.0, hash="poseidon2", hiding=False):
         super().__init__(daemon=True)
         self.hash, self.hiding = hash, hiding
+        self.ahead = not hiding and os.environ.get("P3HIP_BENCH_AHEAD", "0") == "1"
         self.stagger_s = stagger_s
         self.device, self.log_height, self.params = device, log_height, params
         self.inbox, self.outbox = queue.Queue(), queue.Queue()
@@ -50,15 +51,26 @@ class _Worker(threading.Thread):
                         self.stagger_s = 0.0
                     jobs, sink = arg
                     done = []
+
+                    def emit(i, pf):
+                        if sink is not None:
+                            sink(i, pf)  # e.g. straight into the pinned staging row of the step's gather
+                        done.append((i, pf))
+                    ahead = None  # P3HIP_BENCH_AHEAD=1: a second proof enqueued behind the one being collected (helps one prover: +4 %; nothing at four)
                     while True:
                         try:
                             i, a = jobs.get_nowait()
                         except queue.Empty:
                             break
-                        pf = self.prover.prove(a, a + 1)
-                        if sink is not None:
-                            sink(i, pf)  # e.g. straight into the pinned staging row of the step's gather
-                        done.append((i, pf))
+                        if not self.ahead:
+                            emit(i, self.prover.prove(a, a + 1))
+                            continue
+                        self.prover.enqueue(a, a + 1)
+                        if ahead is not None:
+                            emit(ahead, self.prover.finish())
+                        ahead = i
+                    if ahead is not None:
+                        emit(ahead, self.prover.finish())
                     self.outbox.put(("ok", done))
                 elif kind == "stages":
                     self.outbox.put(("ok", self.prover.stage_breakdown()))

@@ -480,6 +480,25 @@ int p3hip_fib_prover_prove(p3hip_fib_prover_t* prover, uint64_t a, uint64_t b, c
     });
 }
 
+int p3hip_fib_prover_enqueue(p3hip_fib_prover_t* prover, uint64_t a, uint64_t b) {
+    return guarded([&]() -> int {
+        if (!prover) return fail(ERR_BAD_ARG, "fib_prover_enqueue: null argument");
+        if (!prover->plain) return fail(ERR_BAD_ARG, "fib_prover_enqueue: the hiding prover proves one proof at a time");
+        return prover->plain->enqueue(a, b);
+    });
+}
+int p3hip_fib_prover_finish(p3hip_fib_prover_t* prover, const uint8_t** proof_out, size_t* proof_len) {
+    return guarded([&]() -> int {
+        if (!prover || !proof_out || !proof_len) return fail(ERR_BAD_ARG, "fib_prover_finish: null argument");
+        if (!prover->plain) return fail(ERR_BAD_ARG, "fib_prover_finish: the hiding prover proves one proof at a time");
+        int rc = prover->plain->finish(&prover->last);
+        if (rc) return rc;
+        *proof_out = prover->last.data();
+        *proof_len = prover->last.size();
+        return OK;
+    });
+}
+
 int p3hip_fib_prover_stage_times(p3hip_fib_prover_t* prover, double out_ms[6], uint64_t* proofs, int reset) {
     if (!prover || !out_ms) return fail(ERR_BAD_ARG, "fib_prover_stage_times: null argument");
     if (!prover->plain) return fail(ERR_BAD_ARG, "fib_prover_stage_times: not kept by the hiding prover");

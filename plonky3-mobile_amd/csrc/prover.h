@@ -26,12 +26,17 @@ class FibProver {
     int init(uint32_t log_n, const FriParams& fp, hipStream_t stream, bool own_stream, int hash = 0);  // mmcs.h HashKind
     // proves the FibonacciAir instance with first row (a, b); public values [a, b, last right value]
     int prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof);
+    // the same in two halves: enqueue returns once the proof's launches are queued (at most two proofs in flight, the second
+    // behind the first on the prover's stream); finish waits for the oldest one and serialises it
+    int enqueue(uint64_t a, uint64_t b);
+    int finish(std::vector<uint8_t>* proof);
     const StageTimes& times() const;
     void reset_times();
 
   private:
     struct Impl;
     Impl* im;
+    int run(uint64_t a, uint64_t b, int slot, int phase, std::vector<uint8_t>* proof, void* pending_rec);
 };
 
 // The same prover for the HIDING half of the reference's configuration (native/src/fib_air.rs:40-65:

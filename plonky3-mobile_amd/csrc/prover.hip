@@ -13,6 +13,7 @@
 // All of these passes are HBM- or integer-VALU-bound element-wise / reduction kernels: one lane per row,
 // 16-byte accesses, no MFMA.
 #include <chrono>
+#include <deque>
 #include <memory>
 #include <cstring>
 
@@ -564,9 +565,15 @@ struct FibProver::Impl {
     uint32_t *partials = nullptr, *qidx = nullptr, *pstage = nullptr, *fp_ev = nullptr;
     DevState* ds = nullptr;
     QTree* qtrees = nullptr;
-    uint32_t* host_stage = nullptr;  // pinned: the proof staging buffer lands here, one copy per proof
+    // pinned: the proof staging buffer lands here, one copy per proof.  Two slots (and two sets of stage events): a second
+    // proof may be enqueued behind the first on the same stream before the first is collected (enqueue / finish)
+    uint32_t* host_stage[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    struct Pending { uint64_t a, b; int slot; std::chrono::steady_clock::time_point t_start, t_enq; uint64_t seq; };
+    std::deque<Pending> pending;
+    uint64_t next_seq = 1, arena_owner = 0;  // arena_owner: the proof whose launch sequence ran last (its state is in the arena)
     StageLayout lay;
-    hipEvent_t ev[N_STAGE_EVENTS] = {nullptr};
+    hipEvent_t ev[2][N_STAGE_EVENTS] = {{nullptr}, {nullptr}};
     std::vector<void*> allocs;
     uint32_t n_rounds = 0;
     std::vector<size_t> fri_vec_off, fri_layer_off;  // word offsets per round
@@ -575,8 +582,9 @@ struct FibProver::Impl {
     StageTimes times{};
     ~Impl() {
         for (void* p : allocs) (void)hipFree(p);
-        if (host_stage) (void)hipHostFree(host_stage);
-        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        for (auto* h : host_stage) if (h) (void)hipHostFree(h);
+        for (auto& set : ev) for (auto& e : set) if (e) (void)hipEventDestroy(e);
+        for (auto& e : done) if (e) (void)hipEventDestroy(e);
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
     int alloc(uint32_t** p, size_t words) {
@@ -653,8 +661,9 @@ int FibProver::init(uint32_t log_n, const FriParams& fp, hipStream_t stream, boo
     uint32_t* qt = nullptr;
     if ((rc = s.alloc(&qt, (sizeof(QTree) / 4) * (s.n_rounds + 2)))) return rc;
     s.qtrees = reinterpret_cast<QTree*>(qt);
-    P3_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.host_stage), stage_words * 4 + 64));
-    for (auto& e : s.ev) P3_HIP(hipEventCreate(&e));
+    for (auto& h : s.host_stage) P3_HIP(hipHostMalloc(reinterpret_cast<void**>(&h), stage_words * 4 + 64));
+    for (auto& set : s.ev) for (auto& e : set) P3_HIP(hipEventCreate(&e));
+    for (auto& e : s.done) P3_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     // device descriptors of the trees opened per query (fixed for the prover's lifetime)
     std::vector<QTree> qd;
     uint32_t off = 0;
@@ -700,14 +709,44 @@ static int get_selectors(Context& cx, hipStream_t stream, uint32_t log_n, const 
 // landed in pinned memory.  The only other synchronisations are the rare continuation of a proof-of-work search whose
 // first range (16x the expected number of candidates) held no witness.
 int FibProver::prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof) {
+    if (!im->pending.empty()) return fail(ERR_BAD_ARG, "fib prover: finish the enqueued proofs before a synchronous prove");
+    int rc = enqueue(a, b);
+    if (rc) return rc;
+    return finish(proof);
+}
+// enqueue: everything up to the copy of the staging buffer into pinned memory, plus an event behind it; returns at once.
+// At most two proofs may be in flight (the second one's kernels simply queue behind the first on the prover's stream: the
+// arena is reused in stream order, the two results land in different pinned buffers).  finish: waits for the OLDEST one,
+// continues an empty proof-of-work search if need be, serialises.
+int FibProver::enqueue(uint64_t a, uint64_t b) {
     Impl& s = *im;
+    if (s.pending.size() >= 2) return fail(ERR_BAD_ARG, "fib prover: two proofs already in flight (finish one first)");
+    const int slot = s.pending.empty() ? 0 : 1 - s.pending.back().slot;
+    Impl::Pending p{a, b, slot, std::chrono::steady_clock::now(), {}, s.next_seq++};
+    int rc = run(a, b, slot, 0, nullptr, &p);
+    if (rc) return rc;
+    s.pending.push_back(p);
+    return OK;
+}
+int FibProver::finish(std::vector<uint8_t>* proof) {
+    Impl& s = *im;
+    if (s.pending.empty()) return fail(ERR_BAD_ARG, "fib prover: no proof in flight");
+    Impl::Pending p = s.pending.front();
+    int rc = run(p.a, p.b, p.slot, 1, proof, &p);
+    s.pending.pop_front();
+    return rc;
+}
+// phase 0: enqueue only; phase 1: collect only
+int FibProver::run(uint64_t a, uint64_t b, int slot, int phase, std::vector<uint8_t>* proof, void* pending_rec) {
+    Impl& s = *im;
+    Impl::Pending& pend = *static_cast<Impl::Pending*>(pending_rec);
+    hipEvent_t* const ev = s.ev[slot];
     Context* cxp;
     int rc = get_context(&cxp);
     if (rc) return rc;
     Context& cx = *cxp;
     if (cx.device != s.device)
         return fail(ERR_BAD_ARG, "fib prover: created on device " + std::to_string(s.device) + ", current device is " + std::to_string(cx.device));
-    const auto t_start = std::chrono::steady_clock::now();
     hipStream_t st = s.stream;
     const uint32_t log_n = s.log_n, log_big = s.log_big;
     const uint32_t n = 1u << log_n, big = 1u << log_big;
@@ -726,96 +765,10 @@ int FibProver::prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof) {
             P3_HIP(hipMemcpyAsync(s.pstage + root_slot, t->layers + t->layer_off.back(), 32, hipMemcpyDeviceToDevice, st));
         return OK;
     };
-    P3_HIP(hipEventRecord(s.ev[0], st));
-
-    // ---- trace + commit (pcs.commit: bit-reversed coset LDE, shift GENERATOR) ----
-    if ((rc = fib_trace(st, a, b, n, s.trace))) return rc;
-    if ((rc = ntt_coset_lde(cx, st, s.trace, s.lde_t, n, 2, s.fp.log_blowup, gen, true))) return rc;
-    if ((rc = commit(s.lde_t, big, 2, s.layers_t, L.root_t))) return rc;
-    hipLaunchKernelGGL(ts_begin_kernel, dim3(1), dim3(64), 0, st, ts, s.trace, n, log_n);
-    P3_HIP(hipGetLastError());
-    P3_HIP(hipEventRecord(s.ev[1], st));
-
-    // ---- quotient values + commit (shift GENERATOR/GENERATOR = 1) ----
-    const uint2* sel = nullptr;
-    if ((rc = get_selectors(cx, st, log_n, &sel))) return rc;
-    {
-        QuotArgs qa{};
-        qa.lde = reinterpret_cast<const uint2*>(s.lde_t);
-        qa.sel = sel;
-        qa.out = s.qflat;
-        qa.ds = s.ds;
-        if ((rc = cx.get_root_table(st, log_n, false, &qa.roots))) return rc;
-        qa.n = n; qa.log_n = log_n; qa.gen = gen; qa.ginv = g_n_inv;
-        qa.zh_inv = bb::inv(bb::sub(bb::pow(gen, n), bb::ONE));
-        hipLaunchKernelGGL(fib_quotient_kernel, dim3((n + 255) / 256), dim3(256), 0, st, qa);
-        P3_HIP(hipGetLastError());
-    }
-    if ((rc = ntt_coset_lde(cx, st, s.qflat, s.lde_q, n, 4, s.fp.log_blowup, bb::ONE, true))) return rc;
-    if ((rc = commit(s.lde_q, big, 4, s.layers_q, L.root_q))) return rc;
-    hipLaunchKernelGGL(ts_zeta_kernel, dim3(1), dim3(64), 0, st, ts, g_n);
-    P3_HIP(hipGetLastError());
-    P3_HIP(hipEventRecord(s.ev[2], st));
-
-    // ---- pcs.open: opened values ----
-    TwoLevelTable roots_big;
-    if ((rc = cx.get_root_table(st, log_big, false, &roots_big))) return rc;
-    {
-        uint32_t threads = (big + DEN_CHUNK - 1) / DEN_CHUNK;
-        hipLaunchKernelGGL(inv_denoms_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, roots_big, big, log_big, gen,
-                           s.ds, s.d0, s.d1);
-        P3_HIP(hipGetLastError());
-        hipLaunchKernelGGL(barycentric_kernel, dim3(s.bary_blocks), dim3(BARY_BLOCK), 0, st, roots_big, n, log_big, gen,
-                           reinterpret_cast<const uint2*>(s.lde_t), reinterpret_cast<const uint4*>(s.lde_q), s.d0, s.d1,
-                           s.partials);
-        P3_HIP(hipGetLastError());
-        const uint32_t sn = bb::pow(gen, n);
-        const uint32_t denom = bb::inv(bb::mul(bb::to_monty(n), sn));
-        hipLaunchKernelGGL(ts_open_kernel, dim3(1), dim3(TS_OPEN_THREADS), 0, st, ts, s.partials, s.bary_blocks, log_n, sn, denom);
-        P3_HIP(hipGetLastError());
-    }
-    P3_HIP(hipEventRecord(s.ev[3], st));
-
-    // ---- reduced openings -> FRI input ----
-    {
-        ReducedArgs ra{};
-        ra.lde_t = reinterpret_cast<const uint2*>(s.lde_t);
-        ra.lde_q = reinterpret_cast<const uint4*>(s.lde_q);
-        ra.d0 = s.d0; ra.d1 = s.d1; ra.ro = s.fri_vec + s.fri_vec_off[0]; ra.big = big;
-        ra.ds = s.ds;
-        hipLaunchKernelGGL(reduced_openings_kernel, dim3((big + 255) / 256), dim3(256), 0, st, ra);
-        P3_HIP(hipGetLastError());
-    }
-
-    // ---- FRI commit phase ----
     const uint32_t one_half = bb::inv(bb::to_monty(2));
-    for (uint32_t r = 0; r < s.n_rounds; r++) {
-        uint32_t len = big >> r, half = len >> 1;
-        // ExtensionMmcs: rows of two ext elements, flattened
-        if ((rc = commit(s.fri_vec + s.fri_vec_off[r], half, 8, s.fri_layers + s.fri_layer_off[r], L.froots + 8 * r))) return rc;
-        hipLaunchKernelGGL(ts_fri_round_kernel, dim3(1), dim3(64), 0, st, ts, r, one_half);
-        P3_HIP(hipGetLastError());
-        TwoLevelTable inv_roots;
-        uint32_t log_half = log_big - 1 - r;
-        if ((rc = cx.get_root_table(st, log_half + 1, true, &inv_roots))) return rc;
-        hipLaunchKernelGGL(fri_fold_kernel, dim3((half + 255) / 256), dim3(256), 0, st, inv_roots,
-                           s.fri_vec + s.fri_vec_off[r], s.fri_vec + s.fri_vec_off[r + 1], half, log_half, s.ds, r, one_half);
-        P3_HIP(hipGetLastError());
-    }
-    // final polynomial: first 2^lfp entries (bit-reversed order) -> natural order -> inverse DFT (of the four base
-    // coordinates: the transform is linear over the base field) straight into the staging buffer
     const uint32_t fpl = 1u << s.fp.log_final_poly_len;
-    if ((rc = bit_reverse_rows(st, s.fri_vec + s.fri_vec_off[s.n_rounds], s.fp_ev, fpl, 4))) return rc;
-    if ((rc = ntt_dft(cx, st, s.fp_ev, s.pstage + L.fpoly, fpl, 4, true))) return rc;
     const uint32_t pow_mask = (1u << s.fp.proof_of_work_bits) - 1u;
-    hipLaunchKernelGGL(ts_final_kernel, dim3(1), dim3(64), 0, st, ts, fpl, pow_mask);
-    P3_HIP(hipGetLastError());
-    P3_HIP(hipEventRecord(s.ev[4], st));
-
-    // ---- proof of work: two launches, no synchronisation.  The first covers 2x the expected number of candidates
-    // (every block of a launch is resident before the first one finishes, so a wider first launch would simply do
-    // all of its work); the second covers up to 16x and its blocks return at once when the first found a witness
-    // (P[first misses] = e^-2, P[both miss] = e^-16: then the host continues the search after the proof's sync).
+    const uint32_t nq = s.fp.num_queries;
     auto grind = [&](uint64_t base, uint32_t count) -> int {
         if (s.hash == HASH_KECCAK) hipLaunchKernelGGL(grind_keccak_kernel, dim3(count / 256), dim3(256), 0, st, s.ds, pow_mask, (uint32_t)base);
         else hipLaunchKernelGGL(grind_kernel, dim3(count / 256), dim3(256), 0, st, s.ds, pow_mask, (uint32_t)base);
@@ -825,15 +778,6 @@ int FibProver::prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof) {
     // P3HIP_GRIND_FIRST_LOG (tests): log2 of the whole first search range, to exercise the continuation path
     const uint32_t first_log = [] { const char* e = getenv("P3HIP_GRIND_FIRST_LOG"); return e ? (uint32_t)atoi(e) : 0u; }();
     uint32_t batch = 1u << std::min<uint32_t>(std::max<uint32_t>(first_log ? first_log : s.fp.proof_of_work_bits + 4, 8), 24);
-    {
-        const uint32_t head = first_log ? batch : std::min<uint32_t>(batch, 1u << std::max<uint32_t>(s.fp.proof_of_work_bits + 1, 8));
-        if ((rc = grind(0, head))) return rc;
-        if (batch > head && (rc = grind(head, batch - head))) return rc;
-    }
-    P3_HIP(hipEventRecord(s.ev[5], st));
-
-    // ---- query phase ----
-    const uint32_t nq = s.fp.num_queries;
     auto queries = [&]() -> int {
         hipLaunchKernelGGL(ts_queries_kernel, dim3(1), dim3(64), 0, st, ts, nq, log_big, s.fp.proof_of_work_bits, s.qidx);
         P3_HIP(hipGetLastError());
@@ -842,20 +786,134 @@ int FibProver::prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof) {
                                (uint32_t)s.slot_words, s.pstage + L.slots);
             P3_HIP(hipGetLastError());
         }
-        P3_HIP(hipMemcpyAsync(s.host_stage, s.pstage, (size_t)L.words * 4, hipMemcpyDeviceToHost, st));
+        P3_HIP(hipMemcpyAsync(s.host_stage[slot], s.pstage, (size_t)L.words * 4, hipMemcpyDeviceToHost, st));
         return OK;
     };
-    if ((rc = queries())) return rc;
-    P3_HIP(hipEventRecord(s.ev[6], st));
-    const auto t_enq = std::chrono::steady_clock::now();
-    P3_HIP(hipStreamSynchronize(st));  // the one synchronisation of a proof
-    const uint32_t* hp = s.host_stage;
+    // the whole launch sequence of one proof (a lambda: finish() runs it again when a proof-of-work search that came up
+    // empty has to be continued after a newer proof has already reused the arena)
+    auto body = [&]() -> int {
+        s.arena_owner = pend.seq;
+        P3_HIP(hipEventRecord(ev[0], st));
+
+        // ---- trace + commit (pcs.commit: bit-reversed coset LDE, shift GENERATOR) ----
+        if ((rc = fib_trace(st, a, b, n, s.trace))) return rc;
+        if ((rc = ntt_coset_lde(cx, st, s.trace, s.lde_t, n, 2, s.fp.log_blowup, gen, true))) return rc;
+        if ((rc = commit(s.lde_t, big, 2, s.layers_t, L.root_t))) return rc;
+        hipLaunchKernelGGL(ts_begin_kernel, dim3(1), dim3(64), 0, st, ts, s.trace, n, log_n);
+        P3_HIP(hipGetLastError());
+        P3_HIP(hipEventRecord(ev[1], st));
+
+        // ---- quotient values + commit (shift GENERATOR/GENERATOR = 1) ----
+        const uint2* sel = nullptr;
+        if ((rc = get_selectors(cx, st, log_n, &sel))) return rc;
+        {
+            QuotArgs qa{};
+            qa.lde = reinterpret_cast<const uint2*>(s.lde_t);
+            qa.sel = sel;
+            qa.out = s.qflat;
+            qa.ds = s.ds;
+            if ((rc = cx.get_root_table(st, log_n, false, &qa.roots))) return rc;
+            qa.n = n; qa.log_n = log_n; qa.gen = gen; qa.ginv = g_n_inv;
+            qa.zh_inv = bb::inv(bb::sub(bb::pow(gen, n), bb::ONE));
+            hipLaunchKernelGGL(fib_quotient_kernel, dim3((n + 255) / 256), dim3(256), 0, st, qa);
+            P3_HIP(hipGetLastError());
+        }
+        if ((rc = ntt_coset_lde(cx, st, s.qflat, s.lde_q, n, 4, s.fp.log_blowup, bb::ONE, true))) return rc;
+        if ((rc = commit(s.lde_q, big, 4, s.layers_q, L.root_q))) return rc;
+        hipLaunchKernelGGL(ts_zeta_kernel, dim3(1), dim3(64), 0, st, ts, g_n);
+        P3_HIP(hipGetLastError());
+        P3_HIP(hipEventRecord(ev[2], st));
+
+        // ---- pcs.open: opened values ----
+        TwoLevelTable roots_big;
+        if ((rc = cx.get_root_table(st, log_big, false, &roots_big))) return rc;
+        {
+            uint32_t threads = (big + DEN_CHUNK - 1) / DEN_CHUNK;
+            hipLaunchKernelGGL(inv_denoms_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, roots_big, big, log_big, gen,
+                               s.ds, s.d0, s.d1);
+            P3_HIP(hipGetLastError());
+            hipLaunchKernelGGL(barycentric_kernel, dim3(s.bary_blocks), dim3(BARY_BLOCK), 0, st, roots_big, n, log_big, gen,
+                               reinterpret_cast<const uint2*>(s.lde_t), reinterpret_cast<const uint4*>(s.lde_q), s.d0, s.d1,
+                               s.partials);
+            P3_HIP(hipGetLastError());
+            const uint32_t sn = bb::pow(gen, n);
+            const uint32_t denom = bb::inv(bb::mul(bb::to_monty(n), sn));
+            hipLaunchKernelGGL(ts_open_kernel, dim3(1), dim3(TS_OPEN_THREADS), 0, st, ts, s.partials, s.bary_blocks, log_n, sn, denom);
+            P3_HIP(hipGetLastError());
+        }
+        P3_HIP(hipEventRecord(ev[3], st));
+
+        // ---- reduced openings -> FRI input ----
+        {
+            ReducedArgs ra{};
+            ra.lde_t = reinterpret_cast<const uint2*>(s.lde_t);
+            ra.lde_q = reinterpret_cast<const uint4*>(s.lde_q);
+            ra.d0 = s.d0; ra.d1 = s.d1; ra.ro = s.fri_vec + s.fri_vec_off[0]; ra.big = big;
+            ra.ds = s.ds;
+            hipLaunchKernelGGL(reduced_openings_kernel, dim3((big + 255) / 256), dim3(256), 0, st, ra);
+            P3_HIP(hipGetLastError());
+        }
+
+        // ---- FRI commit phase ----
+        for (uint32_t r = 0; r < s.n_rounds; r++) {
+            uint32_t len = big >> r, half = len >> 1;
+            // ExtensionMmcs: rows of two ext elements, flattened
+            if ((rc = commit(s.fri_vec + s.fri_vec_off[r], half, 8, s.fri_layers + s.fri_layer_off[r], L.froots + 8 * r))) return rc;
+            hipLaunchKernelGGL(ts_fri_round_kernel, dim3(1), dim3(64), 0, st, ts, r, one_half);
+            P3_HIP(hipGetLastError());
+            TwoLevelTable inv_roots;
+            uint32_t log_half = log_big - 1 - r;
+            if ((rc = cx.get_root_table(st, log_half + 1, true, &inv_roots))) return rc;
+            hipLaunchKernelGGL(fri_fold_kernel, dim3((half + 255) / 256), dim3(256), 0, st, inv_roots,
+                               s.fri_vec + s.fri_vec_off[r], s.fri_vec + s.fri_vec_off[r + 1], half, log_half, s.ds, r, one_half);
+            P3_HIP(hipGetLastError());
+        }
+        // final polynomial: first 2^lfp entries (bit-reversed order) -> natural order -> inverse DFT (of the four base
+        // coordinates: the transform is linear over the base field) straight into the staging buffer
+        if ((rc = bit_reverse_rows(st, s.fri_vec + s.fri_vec_off[s.n_rounds], s.fp_ev, fpl, 4))) return rc;
+        if ((rc = ntt_dft(cx, st, s.fp_ev, s.pstage + L.fpoly, fpl, 4, true))) return rc;
+        hipLaunchKernelGGL(ts_final_kernel, dim3(1), dim3(64), 0, st, ts, fpl, pow_mask);
+        P3_HIP(hipGetLastError());
+        P3_HIP(hipEventRecord(ev[4], st));
+
+        // ---- proof of work: two launches, no synchronisation.  The first covers 2x the expected number of candidates
+        // (every block of a launch is resident before the first one finishes, so a wider first launch would simply do
+        // all of its work); the second covers up to 16x and its blocks return at once when the first found a witness
+        // (P[first misses] = e^-2, P[both miss] = e^-16: then the host continues the search after the proof's sync).
+        {
+            const uint32_t head = first_log ? batch : std::min<uint32_t>(batch, 1u << std::max<uint32_t>(s.fp.proof_of_work_bits + 1, 8));
+            if ((rc = grind(0, head))) return rc;
+            if (batch > head && (rc = grind(head, batch - head))) return rc;
+        }
+        P3_HIP(hipEventRecord(ev[5], st));
+
+        // ---- query phase ----
+        if ((rc = queries())) return rc;
+        P3_HIP(hipEventRecord(ev[6], st));
+        return OK;
+    };
+    if (phase == 0) {
+        if ((rc = body())) return rc;
+        P3_HIP(hipEventRecord(s.done[slot], st));
+        pend.t_enq = std::chrono::steady_clock::now();
+        return OK;
+    }
+    const auto t_start = pend.t_start, t_enq = pend.t_enq;
+    P3_HIP(hipEventSynchronize(s.done[slot]));  // the one synchronisation of a proof
+    const uint32_t* hp = s.host_stage[slot];
     static const bool trace = getenv("P3HIP_TRACE") != nullptr;
 #define TR(...) do { if (trace) { fprintf(stderr, __VA_ARGS__); fflush(stderr); } } while (0)
     TR("prove: enqueued in %.0f us of host time, synced after another %.0f us, status %u\n",
        std::chrono::duration<double, std::micro>(t_enq - t_start).count(),
        std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enq).count(), hp[L.status]);
     if (hp[L.status] == ST_GRIND_MISS) {
+        if (s.arena_owner != pend.seq) {
+            // a newer proof was queued behind this one and has reused the arena: let the stream drain (that proof's result
+            // waits in the other pinned buffer), then run this proof again from the start — it reaches the same empty range
+            P3_HIP(hipStreamSynchronize(st));
+            if ((rc = body())) return rc;
+            P3_HIP(hipStreamSynchronize(st));
+        }
         // continue the search range by range (each 4x the previous one), then redo the query phase
         uint32_t found = 0xffffffffu;
         for (uint64_t base = batch; base < bb::P && found == 0xffffffffu; base += batch) {
@@ -907,7 +965,7 @@ int FibProver::prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof) {
     TR("prove: serialised %zu bytes\n", pf.size());
     // stage times on the device timeline (events between the stages of the stream)
     float ms[N_STAGE_EVENTS - 1] = {0};
-    for (int k = 0; k + 1 < N_STAGE_EVENTS; k++) (void)hipEventElapsedTime(&ms[k], s.ev[k], s.ev[k + 1]);
+    for (int k = 0; k + 1 < N_STAGE_EVENTS; k++) (void)hipEventElapsedTime(&ms[k], ev[k], ev[k + 1]);
     s.times.trace_commit_ms += ms[0]; s.times.quotient_commit_ms += ms[1]; s.times.open_ms += ms[2];
     s.times.fri_commit_ms += ms[3]; s.times.grind_ms += ms[4]; s.times.query_ms += ms[5]; s.times.proofs += 1;
     return OK;

@@ -66,6 +66,17 @@ class FibAirProver:
         _lib.check(_lib.lib().p3hip_fib_prover_prove(self._h, a, b, C.byref(out), C.byref(n)))
         return C.string_at(out, n.value)
 
+    def enqueue(self, a, b):
+        """Queues the proof's launches and returns at once (at most two proofs in flight; not for the hiding prover)."""
+        _lib.check(_lib.lib().p3hip_fib_prover_enqueue(self._h, a, b))
+
+    def finish(self):
+        """Waits for the oldest enqueued proof and returns its bytes."""
+        out = C.POINTER(C.c_uint8)()
+        n = C.c_size_t()
+        _lib.check(_lib.lib().p3hip_fib_prover_finish(self._h, C.byref(out), C.byref(n)))
+        return C.string_at(out, n.value)
+
     @staticmethod
     def proof_bytes(proof):
         return proof

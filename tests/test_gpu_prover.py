@@ -128,6 +128,32 @@ def test_batch_pool_submit_collect(p3, oracle):
         pool.close()
 
 
+@pytest.mark.parametrize("hash", ["poseidon2", "keccak"])
+def test_enqueue_finish_two_proofs_in_flight(p3, oracle, hash):
+    """enqueue / finish: the second proof's launches queue behind the first on the prover's stream; results come back in
+    order, byte for byte; a third enqueue and a finish with nothing in flight are refused; prove() still works after."""
+    gfp, ofp = _fp(p3, oracle, 1, 0, 14, 6)
+    kind = oracle.HASH_KECCAK if hash == "keccak" else oracle.HASH_POSEIDON2
+    pr = p3.FibAirProver(10, params=gfp, hash=hash)
+    ref = [oracle.prove_fib_air(a, a + 1, 10, ofp, hash=kind) for a in range(5)]
+    pr.enqueue(0, 1)
+    pr.enqueue(1, 2)
+    with pytest.raises(p3.P3HipError):
+        pr.enqueue(2, 3)
+    with pytest.raises(p3.P3HipError):
+        pr.prove(2, 3)  # synchronous prove with proofs in flight
+    assert pr.finish() == ref[0]
+    pr.enqueue(2, 3)
+    assert pr.finish() == ref[1]
+    pr.enqueue(3, 4)
+    assert pr.finish() == ref[2]
+    assert pr.finish() == ref[3]
+    with pytest.raises(p3.P3HipError):
+        pr.finish()
+    assert pr.prove(4, 5) == ref[4]
+    pr.close()
+
+
 def test_bad_parameters(p3, oracle):
     with pytest.raises(p3.P3HipError):
         p3.FibAirProver(0)
@@ -209,4 +235,11 @@ def test_grind_search_continues_after_an_empty_first_range(p3, oracle, hash, mon
         witness = int(np.frombuffer(proof[-4:], np.uint32)[0])
         hit_continuation |= int(oracle.from_monty(np.array([witness]))[0]) >= 256
     assert hit_continuation, "no instance needed the continuation path: pick other instances"
+    # the same with two proofs in flight: when the older one needs the continuation its arena has been reused by the
+    # newer one, so finish() runs it again from the start before continuing the search
+    pr.enqueue(0, 1)
+    for a in range(1, 4):
+        pr.enqueue(a, a + 1)
+        assert pr.finish() == oracle.prove_fib_air(a - 1, a, 9, ofp, hash=kind)
+    assert pr.finish() == oracle.prove_fib_air(3, 4, 9, ofp, hash=kind)
     pr.close()

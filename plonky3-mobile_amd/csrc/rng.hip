@@ -185,6 +185,7 @@ __global__ void __launch_bounds__(64) rng_pass1_kernel(const DevRng* st, const u
 // (One workgroup walking the whole array took 183 us for the 2^17.8 chunks of the prover's largest fill.)
 constexpr uint32_t SCAN_TILE = 1024;
 __global__ void __launch_bounds__(256) rng_scan_tiles_kernel(uint32_t* counts, uint32_t n, uint32_t* bsum) {
+    P3_LATENCY_BOUND_KERNEL();
     __shared__ uint32_t wsum[4];
     const uint32_t tid = threadIdx.x, base = blockIdx.x * SCAN_TILE + tid * 4, lane = tid & 63u, wv = tid >> 6;
     uint32_t c[4];
@@ -209,6 +210,7 @@ __global__ void __launch_bounds__(256) rng_scan_tiles_kernel(uint32_t* counts, u
     if (tid == 255) bsum[blockIdx.x] = run;
 }
 __global__ void __launch_bounds__(1024) rng_scan_kernel(uint32_t* counts, uint32_t n) {  // n <= 4096 block totals
+    P3_LATENCY_BOUND_KERNEL();
     __shared__ uint32_t part[1024];
     const uint32_t per = (n + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
     uint32_t sum = 0;

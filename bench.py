@@ -3,12 +3,16 @@
 blowup 2, on N MI355X (one process per GPU; proofs are independent, so ranks shard the batch with no
 data-path collective — weak scaling).
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
-  python bench.py --workload cfg3|cfg5 ...                (the other single-GPU BASELINE configs, same JSON schema)
+  python bench.py --gpus N --steps K --warmup W          (N>1 under torch.distributed.run: WORLD_SIZE/RANK from the env;
+                                                           N>1 WITHOUT a launcher: this process starts N rank processes itself,
+                                                           before it has touched the GPU, relays rank 0's line, exits with their rc)
+  python bench.py --workload cfg3|cfg4|cfg5 ...           (the other BASELINE configs, same JSON schema)
 
 Workloads (BASELINE.json `configs`):
   cfg2 (default)  configs[1]: fib_air 2^20-row trace, blowup 2.  A "step" proves `--batch` independent instances
                   (a, b) = (i, i+1) per rank with all inputs generated in HBM.
+  cfg4            configs[3]: a batch of 64 independent 2^20 proofs in TOTAL per step, instance i -> rank i mod N
+                  (strong scaling: the per-rank share shrinks as N grows); rank 0 scatters descriptors, gathers proof bytes.
   cfg3            configs[2]: fib_air 2^24-row trace, blowup 4 (FRI-fold-heavy); step = `--batch` proofs.
   cfg5            configs[4]: the wide trace 2^16 x 2633 (benchmark_input, fib_air.rs:77-86, standing in for the
                   Keccak-f AIR trace): step = one bit-reversed coset LDE (blowup 2) + Poseidon2 MMCS commit of
@@ -119,13 +123,63 @@ def cpu_baseline_wide(job):
             "seconds_estimated_whole_job": est, "lde_columns_equal_to_gpu": same, "leaf_digests_equal_to_gpu": same_d}
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with no launcher around it: start N fresh rank processes (one per GPU) with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relay rank 0's JSON line, return the worst exit code.  This parent has
+    not touched the GPU (torch.cuda.device_count() does not initialise it on this image) and never execs."""
+    import socket
+    import subprocess
+    backend = os.environ.get("P3HIP_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            print("bench.py: --gpus %d but this node shows %d GPU(s); refusing to fake an N-GPU line "
+                  "(P3HIP_BENCH_BACKEND=gloo rehearses the N-rank path on fewer GPUs)" % (n, have), file=sys.stderr)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), P3HIP_BENCH_LAUNCHED_BY="bench.py")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    # a rank that dies before the rendezvous would leave the others waiting for it: once one has failed, the rest get 20 s
+    deadline = None
+    while any(p.poll() is None for p in procs):
+        if deadline is None and any(p.poll() not in (None, 0) for p in procs):
+            deadline = time.monotonic() + 20.0
+        if deadline is not None and time.monotonic() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()  # exactly the children started above
+        time.sleep(0.05)
+    rcs = [p.wait() for p in procs]
+    reader.join(5.0)
+    sys.stdout.write(b"".join(chunks).decode())
+    sys.stdout.flush()
+    bad = [rc for rc in rcs if rc != 0]
+    if bad:
+        print("bench.py: rank exit codes %r" % (rcs,), file=sys.stderr)
+        return max(abs(rc) for rc in bad) or 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg5"], default="cfg2",
-                    help="BASELINE configs[1] (default, the headline), configs[2] or configs[4]")
+    ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg4", "cfg5"], default="cfg2",
+                    help="BASELINE configs[1] (default, the headline), configs[2], configs[3] (64 proofs in total per step over the "
+                         "ranks) or configs[4]")
     ap.add_argument("--log-height", type=int, default=None)
     ap.add_argument("--log-blowup", type=int, default=None)
     ap.add_argument("--batch", type=int, default=None, help="independent proofs per rank per step")
@@ -137,9 +191,25 @@ def main():
                     help="the reference's hiding configuration (MerkleTreeHidingMmcs + HidingFriPcs, fib_air.rs:40-65); with --hash keccak "
                          "this is exactly what the reference runs")
     args = ap.parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if env_world is not None and args.gpus > 1 and int(env_world) != args.gpus:
+        print("bench.py: --gpus %d contradicts WORLD_SIZE=%s" % (args.gpus, env_world), file=sys.stderr)
+        sys.exit(2)
     defaults = {"cfg2": dict(log_height=20, log_blowup=1, batch=32, threads=4, steps=20, warmup=2),
+                "cfg4": dict(log_height=20, log_blowup=1, batch=None, threads=4, steps=10, warmup=1),
                 "cfg3": dict(log_height=24, log_blowup=2, batch=4, threads=2, steps=3, warmup=1),
                 "cfg5": dict(log_height=16, log_blowup=1, batch=1, threads=1, steps=10, warmup=2)}[args.workload]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    CFG4_TOTAL = 64  # BASELINE configs[3]: "batch of 64 independent fib_air 2^20 proofs"
+    if args.workload == "cfg4" and args.batch is None:
+        if CFG4_TOTAL % world:
+            print("bench.py: cfg4 splits 64 proofs over the ranks; %d ranks do not divide 64" % world, file=sys.stderr)
+            sys.exit(2)
+        args.batch = CFG4_TOTAL // world
     for k, v in defaults.items():
         if getattr(args, k) is None:
             setattr(args, k, v)
@@ -149,11 +219,12 @@ def main():
     from __graft_entry__ import load_package
     p3 = load_package()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # P3HIP_BENCH_STUB=1 (tests only): the CLI, the rank launcher and the scatter / gather loop with a job that proves
+    # nothing and touches no GPU; its line says so in `metric` and `data` and can not be mistaken for a measurement.
+    stub = os.environ.get("P3HIP_BENCH_STUB") == "1"
     n_dev = torch.cuda.device_count()
-    torch.cuda.set_device(local_rank % max(n_dev, 1))
+    if not stub:
+        torch.cuda.set_device(local_rank % max(n_dev, 1))
     # backend "nccl" IS RCCL on ROCm.  P3HIP_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with
     # fewer GPUs than ranks (collectives then move host tensors).
     backend = os.environ.get("P3HIP_BENCH_BACKEND", "nccl")
@@ -170,6 +241,13 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+    if stub:
+        if backend == "nccl":
+            raise RuntimeError("P3HIP_BENCH_STUB=1 needs P3HIP_BENCH_BACKEND=gloo")
+        if os.environ.get("P3HIP_BENCH_STUB_FAIL") == "1" and rank == world - 1:
+            raise RuntimeError("P3HIP_BENCH_STUB_FAIL=1: this rank fails on purpose (launcher test)")
+        job = StubJob(args.batch, first_instance=rank * args.batch)
+        return run(args, job, dist, world, rank, local_rank, n_dev, backend, coll_dev, use_dist, defaults, stub)
     ok, msg = p3.is_available()
     if not ok:
         raise RuntimeError("no HIP backend, refusing to run a fallback: " + msg)
@@ -181,12 +259,66 @@ def main():
         job = bs.FibAirJob(p3, args.log_height, args.log_blowup, args.batch, first_instance=rank * args.batch,
                            threads=args.threads, hash=args.hash, hiding=args.hiding, config_label={"cfg2": "configs[1]", "cfg3": "configs[2]"}.get(
                                args.workload if (args.log_height, args.log_blowup) == (defaults["log_height"], defaults["log_blowup"]) else ""))
+    return run(args, job, dist, world, rank, local_rank, n_dev, backend, coll_dev, use_dist, defaults, stub)
+
+
+class StubJob:
+    """Stands in for FibAirJob under P3HIP_BENCH_STUB=1 (CPU tests of the CLI / launcher / collectives): a "proof" is 64
+    bytes derived from the instance.  Nothing here is a measurement."""
+
+    def __init__(self, batch, first_instance=0):
+        self.batch, self.first, self._steps = batch, first_instance, []
+
+    def step_begin(self, instances=None, sink=None):
+        todo = instances if instances is not None else [(i, self.first + i) for i in range(self.batch)]
+        got = {}
+        for i, a in todo:
+            pf = (b"STUB" + int(a).to_bytes(8, "little")) * 5 + b"\0" * 4
+            if sink is not None:
+                sink(i, pf)
+            got[i] = pf
+        self._steps.append(got)
+
+    def step_end(self):
+        return self._steps.pop(0)
+
+    def prove_one(self, a, b):
+        return (b"STUB" + int(a).to_bytes(8, "little")) * 5 + b"\0" * 4
+
+    def metric_name(self):
+        return "STUB (no proofs were computed)"
+
+    def unit(self):
+        return "stub-units/s"
+
+    def config(self):
+        return {"batch_per_gpu": self.batch}
+
+    def workload_name(self):
+        return "STUB job (P3HIP_BENCH_STUB=1): CLI / launcher / scatter-gather rehearsal without a GPU"
+
+    def roofline(self):
+        return None
+
+    def extra_report(self):
+        return {}
+
+    def close(self):
+        pass
+
+
+def run(args, job, dist, world, rank, local_rank, n_dev, backend, coll_dev, use_dist, defaults, stub):
+    import torch
+
+    def gpu_sync():
+        if not stub:
+            torch.cuda.synchronize()
 
     def barrier():
-        torch.cuda.synchronize()
+        gpu_sync()
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        gpu_sync()
 
     from plonky3_mobile_amd import batch as pbatch
     n_total = args.batch * world
@@ -270,12 +402,13 @@ def main():
     run_steps(args.warmup, args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    ranks_info = [{"rank": rank, "local_rank": local_rank, "device_count": n_dev, "device": torch.cuda.current_device()}]
+    cur_dev = -1 if stub else torch.cuda.current_device()
+    ranks_info = [{"rank": rank, "local_rank": local_rank, "device_count": n_dev, "device": cur_dev}]
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        info = torch.tensor([rank, local_rank, n_dev, torch.cuda.current_device()], dtype=torch.int64, device=coll_dev)
+        info = torch.tensor([rank, local_rank, n_dev, cur_dev], dtype=torch.int64, device=coll_dev)
         infos = [torch.empty_like(info) for _ in range(world)]
         dist.all_gather(infos, info)
         ranks_info = [dict(zip(("rank", "local_rank", "device_count", "device"), [int(v) for v in i.cpu().tolist()])) for i in infos]
@@ -292,11 +425,13 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if args.workload == "cfg4" else "weak",
         "vs_baseline": None,
         "dtype": "u32 (BabyBear Montgomery, 31-bit modular)",
-        "data": "synthetic",
-        "config": dict(job.config(), workload=job.workload_name(), hash=args.hash,
+        "data": "synthetic" if not stub else "STUB: nothing was proved, no GPU was used (P3HIP_BENCH_STUB=1)",
+        "config": dict(job.config(), workload=job.workload_name() + (
+                           "; BASELINE configs[3]: %d proofs in total per step, instance i -> rank i mod %d" % (n_total, world)
+                           if args.workload == "cfg4" else ""), hash=args.hash, total_batch_per_step=n_total,
                        step_pipelining="depth 1: step k+1's instances are dealt to the prover threads before step k's last proofs "
                                        "finish; all K steps complete inside the timed region",
                        parallelism=("independent proofs, instance i -> rank i mod N; RCCL only scatters descriptors / gathers proof bytes"
@@ -310,7 +445,11 @@ def main():
                   "recall; pinned by reference code only for the DFT): self-consistent, upstream parity UNPINNED",
     }
     out.update(job.extra_report())
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if world > 1:
+        out["cpu_baseline"] = "omitted for world > 1 (the CPU leg is timed by the N=1 run only)"
+    elif stub or args.no_cpu_baseline:
+        out["cpu_baseline"] = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not stub:
         if args.workload == "cfg5":
             out["cpu_baseline"] = cpu_baseline_wide(job)
         else:

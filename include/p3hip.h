@@ -194,6 +194,12 @@ int p3hip_fib_prover_finish(p3hip_fib_prover_t *prover, const uint8_t **proof_ou
 /* host wall-clock per stage [trace commit, quotient commit, open, FRI commit phase, grind, queries] in ms,
  * accumulated over *proofs proofs */
 int p3hip_fib_prover_stage_times(p3hip_fib_prover_t *prover, double out_ms[6], uint64_t *proofs, int reset);
+/* Diagnostics of the proof-of-work continuation path (no reference counterpart: p3_fri grinds on the host).  *misses = proofs
+ * of this prover whose first device search range held no witness; indices_out[0..min(cap, *n_out)) = the device's query-index
+ * buffer as it stood when the host learnt of the LAST miss, before the search continued: all zero by construction, because
+ * the gather kernel queued behind the query kernel reads that buffer whatever the search returned. */
+int p3hip_fib_prover_grind_miss_probe(p3hip_fib_prover_t *prover, uint64_t *misses, uint32_t *indices_out, size_t cap,
+                                      size_t *n_out);
 void p3hip_fib_prover_destroy(p3hip_fib_prover_t *prover);
 /* verify(&config, &FibonacciAir{}, &proof, &pis) (native/src/fib_air.rs:71-72) with pis = [a, b, x]: host-side, a few
  * thousand permutations.  Returns 0 to accept, a positive code naming the failed check otherwise (message via

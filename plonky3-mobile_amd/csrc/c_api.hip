@@ -510,6 +510,16 @@ int p3hip_fib_prover_stage_times(p3hip_fib_prover_t* prover, double out_ms[6], u
     return OK;
 }
 
+int p3hip_fib_prover_grind_miss_probe(p3hip_fib_prover_t* prover, uint64_t* misses, uint32_t* indices_out, size_t cap, size_t* n_out) {
+    if (!prover || !misses) return fail(ERR_BAD_ARG, "fib_prover_grind_miss_probe: null argument");
+    if (!prover->plain) return fail(ERR_BAD_ARG, "fib_prover_grind_miss_probe: not kept by the hiding prover");
+    std::vector<uint32_t> idx;
+    *misses = prover->plain->grind_misses(&idx);
+    if (n_out) *n_out = idx.size();
+    if (indices_out) for (size_t i = 0; i < idx.size() && i < cap; i++) indices_out[i] = idx[i];
+    return OK;
+}
+
 void p3hip_fib_prover_destroy(p3hip_fib_prover_t* prover) { delete prover; }
 
 int p3hip_fib_prover_create_hiding(int hash, unsigned log_n, const p3hip_fri_params_t* params, uint64_t seed, void* stream,

@@ -71,6 +71,7 @@ struct CachedTable {  // a table built by a kernel on `built_on`; other streams 
 struct Context {
     int device = -1;
     uint32_t* tile_tw[2] = {nullptr, nullptr};  // [inverse]: reference-layout stage tables, 2^12-1 words
+    double2* tile_twd[2] = {nullptr, nullptr};  // the same tables as {w, w / P} doubles of canonical values (fp64 kernels)
     std::map<std::pair<uint32_t, int>, CachedTable> root_tables;                   // (q, inverse) -> w_{2^q}^e
     std::map<std::tuple<uint32_t, uint32_t, uint32_t>, CachedTable> scale_tables;  // (base, log_n, mult)
     std::map<std::pair<hipStream_t, int>, DevBuf> scratch;                         // (stream, slot)

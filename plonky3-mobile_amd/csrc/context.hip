@@ -79,6 +79,13 @@ int Context::init(int dev) {
         }
         int rc = upload(t, &tile_tw[invs]);
         if (rc) return rc;
+        std::vector<double2> td(1u << 12, double2{0.0, 0.0});
+        for (uint32_t i = 0; i + 1 < (1u << 12); i++) {
+            const double w = (double)bb::from_monty(t[i]);
+            td[i] = double2{w, w / 2013265921.0};
+        }
+        P3_HIP(hipMalloc(reinterpret_cast<void**>(&tile_twd[invs]), td.size() * sizeof(double2)));
+        P3_HIP(hipMemcpy(tile_twd[invs], td.data(), td.size() * sizeof(double2), hipMemcpyHostToDevice));
     }
     device = dev;
     return OK;
@@ -183,6 +190,7 @@ Context::~Context() {
     for (auto& kv : scale_tables) free_table(kv.second);
     for (auto& kv : selector_tables) free_table(kv.second);
     for (int i = 0; i < 2; i++) if (tile_tw[i]) (void)hipFree(tile_tw[i]);
+    for (int i = 0; i < 2; i++) if (tile_twd[i]) (void)hipFree(tile_twd[i]);
     if (rng_jump) (void)hipFree(rng_jump);
 }
 

@@ -136,6 +136,7 @@ __device__ __forceinline__ uint32_t two_level(const uint32_t* lo, const uint32_t
 }  // namespace p3
 #include "ntt_fast.hip.h"
 #include "ntt_narrow.hip.h"
+#include "ntt_narrow_f64.hip.h"
 namespace p3 {
 
 // Decodes a copy-loop index into tile coordinates (pt, x), the global word offset and the natural row
@@ -854,6 +855,53 @@ int launch_narrow(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t
     return vw == 1 ? launch_narrow_v<K, 1>(cx, stream, a, b, blocks, gy) : launch_narrow_v<K, 2>(cx, stream, a, b, blocks, gy);
 }
 
+// fp64 forms (ntt_narrow_f64.hip.h).  NT = 2 LDS tiles (one barrier per hand-over) where they fit and the grid gives a CU
+// one workgroup anyway; otherwise one tile, so that two workgroups can share a CU.
+template <int B, int LQ, int VW, int K, int NT>
+int launch_narrow64_nt(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t blocks, uint32_t grid_y) {
+    constexpr size_t lds = narrow64::lds_bytes<B, LQ, VW, NT>(K == 2 ? 2 : 1);
+    static_assert(lds <= 160 * 1024, "fp64 narrow tile does not fit the LDS");
+    void (*kern)(NarrowArgs);
+    if constexpr (K == 1) kern = narrow64_inv1_kernel<B, LQ, VW, NT>;
+    else if constexpr (K == 2) kern = narrow64_mid_kernel<B, LQ, VW, NT, (VW == 2)>;
+    else kern = narrow64_fwd2_kernel<B, LQ, VW, NT>;
+    if constexpr (lds > 64 * 1024) {
+        int rc = cx.ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks, K == 2 ? grid_y : 1u), dim3(1u << (B - 4 + LQ)), lds, stream, a);
+    P3_HIP(hipGetLastError());
+    return OK;
+}
+template <int B, int LQ, int VW, int K>
+int launch_narrow64_t(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t blocks, uint32_t grid_y) {
+    constexpr bool fits2 = narrow64::lds_bytes<B, LQ, VW, 2>(K == 2 ? 2 : 1) <= 160 * 1024;
+    static int nt_env = [] { const char* e = getenv("P3HIP_NTT_NARROW_F64_TILES"); return e ? atoi(e) : 0; }();
+    if constexpr (fits2) {
+        const bool two = nt_env ? nt_env == 2 : (size_t)blocks * grid_y <= 256 || narrow64::lds_bytes<B, LQ, VW, 2>(K == 2 ? 2 : 1) <= 80 * 1024;
+        if (two) return launch_narrow64_nt<B, LQ, VW, K, 2>(cx, stream, a, blocks, grid_y);
+    }
+    return launch_narrow64_nt<B, LQ, VW, K, 1>(cx, stream, a, blocks, grid_y);
+}
+// 1024-thread workgroups (128 VGPRs per lane) are left to the integer kernels: K2 at single columns from 11 stages on
+constexpr bool narrow64_has(int b, int vw, int k) { return b - 4 + narrow_lq(b, vw) <= (k == 2 ? 9 : 10); }
+template <int K, int VW>
+int launch_narrow64_v(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t b, uint32_t blocks, uint32_t gy) {
+#define P3_N64_CASE(BB)                                                                                          \
+    case BB:                                                                                                     \
+        if constexpr (narrow64_has(BB, VW, K)) return launch_narrow64_t<BB, narrow_lq(BB, VW), VW, K>(cx, stream, a, blocks, gy); \
+        else return fail(ERR_INTERNAL, "lde_narrow: fp64 shape not instantiated");
+    switch (b) {
+        P3_N64_CASE(8) P3_N64_CASE(9) P3_N64_CASE(10) P3_N64_CASE(11) P3_N64_CASE(12)
+        default: return fail(ERR_INTERNAL, "lde_narrow: digit out of range");
+    }
+#undef P3_N64_CASE
+}
+template <int K>
+int launch_narrow64(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t b, uint32_t blocks, int vw, uint32_t gy = 1) {
+    return vw == 1 ? launch_narrow64_v<K, 1>(cx, stream, a, b, blocks, gy) : launch_narrow64_v<K, 2>(cx, stream, a, b, blocks, gy);
+}
+
 // Narrow-matrix coset LDE in three launches (ntt_narrow.hip.h).  Returns 1 when the shape is not covered.
 int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* dst, uint32_t n, uint32_t added, uint32_t W,
                uint32_t shift, bool bit_reversed_out) {
@@ -899,11 +947,47 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     a.src = src; a.dst = T;
     a.stage_tw = cx.tile_tw[1];
     a.tw_lo = ti.lo; a.tw_hi = ti.hi; a.tw_T = ti.T;
+    // fp64 butterflies (6 instructions instead of 12, ntt_narrow_f64.hip.h).  Measured (profiles/r03_lde_f64_vs_int.txt): the
+    // VALU instructions per wave drop by a third, but the exchanges move doubles, so the unit gains only 3-8 % up to 2^19 rows
+    // and at 2^20 x 2, and LOSES from 2^21 rows on, where twice the LDS per workgroup halves the waves per SIMD.  Default:
+    // fp64 where it wins; P3HIP_NTT_NARROW_F64 = 0 keeps the integer kernels, 1..7 is a bit mask (1 = K1, 2 = K2, 4 = K3).
+    static int f64_env = [] { const char* e = getenv("P3HIP_NTT_NARROW_F64"); return e ? atoi(e) : -1; }();
+    const int f64_mask = f64_env >= 0 ? f64_env : ((n <= 19 || (n == 20 && W == 2)) ? 7 : 0);
+    auto f64 = [&](int k, uint32_t b) {
+        if (!((f64_mask >> k) & 1)) return false;
+        return b - 4 + (uint32_t)narrow_lq((int)b, vw[k]) <= (k == 1 ? 9u : 10u);
+    };
+    a.stage_twd = cx.tile_twd[1];
+    a.neg_pm1 = -2013265920.0; a.pinv = 1.0 / 2013265921.0; a.fbias = -0.5 + 1.0 / 8589934592.0;
     uint32_t tiles = geometry(0, n1, 1ull << n2);
-    if ((rc = launch_narrow<1>(cx, stream, a, n1, tiles, vw[0]))) return rc;
+#if NARROW_STAMPS
+    // diagnostic build: P3HIP_NTT_STAMPS=<file> appends K1's per-workgroup phase stamps (32 u64 each) after every call
+    static const char* stamp_path = getenv("P3HIP_NTT_STAMPS");
+    if (stamp_path) {
+        if ((rc = cx.ws(stream, 7).reserve((size_t)tiles * 32 * 8))) return rc;
+        a.stamps = cx.ws(stream, 7).as<unsigned long long>();
+        P3_HIP(hipMemsetAsync(a.stamps, 0, (size_t)tiles * 32 * 8, stream));
+    }
+#endif
+    if ((rc = f64(0, n1) ? launch_narrow64<1>(cx, stream, a, n1, tiles, vw[0]) : launch_narrow<1>(cx, stream, a, n1, tiles, vw[0]))) return rc;
+#if NARROW_STAMPS
+    if (a.stamps) {
+        std::vector<unsigned long long> h((size_t)tiles * 32);
+        P3_HIP(hipStreamSynchronize(stream));
+        P3_HIP(hipMemcpy(h.data(), a.stamps, h.size() * 8, hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(stamp_path, "ab")) {
+            uint32_t hdr[4] = {n, W, added, tiles};
+            fwrite(hdr, 4, 4, f);
+            fwrite(h.data(), 8, h.size(), f);
+            fclose(f);
+        }
+        a.stamps = nullptr;
+    }
+#endif
     // K2
     a.src = T; a.dst = dst;
     a.stage_tw = cx.tile_tw[1]; a.stage_tw_fwd = cx.tile_tw[0];
+    a.stage_twd = cx.tile_twd[1]; a.stage_twd_fwd = cx.tile_twd[0];
     a.twf_lo = tf.lo; a.twf_hi = tf.hi; a.twf_T = tf.T;
     const uint32_t hinv = bb::inv(bb::to_monty((uint32_t)N));
     const uint32_t g = bb::two_adic_generator(n + added);
@@ -926,12 +1010,14 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     if (cos_split < 0) { while (split_log < added && ((uint64_t)tiles << (split_log + 1)) <= 256) split_log++; }
     else split_log = std::min<uint32_t>((uint32_t)cos_split, added);
     a.cos_per_block = (1u << added) >> split_log;
-    if ((rc = launch_narrow<2>(cx, stream, a, n2, tiles, vw[1], 1u << split_log))) return rc;
+    if ((rc = f64(1, n2) ? launch_narrow64<2>(cx, stream, a, n2, tiles, vw[1], 1u << split_log)
+                         : launch_narrow<2>(cx, stream, a, n2, tiles, vw[1], 1u << split_log))) return rc;
     // K3
     a.src = dst; a.dst = dst;
     a.stage_tw = cx.tile_tw[0];
+    a.stage_twd = cx.tile_twd[0];
     tiles = geometry(2, n1, (1ull << added) << n2);
-    return launch_narrow<3>(cx, stream, a, n1, tiles, vw[2]);
+    return f64(2, n1) ? launch_narrow64<3>(cx, stream, a, n1, tiles, vw[2]) : launch_narrow<3>(cx, stream, a, n1, tiles, vw[2]);
 }
 
 }  // namespace

@@ -55,7 +55,35 @@
 #ifndef NARROW_MID_SHARE_CU
 #define NARROW_MID_SHARE_CU 0
 #endif
+#ifndef NARROW_STAMPS
+#define NARROW_STAMPS 0  // diagnostic builds only (tools/_bin): wave 0 of every workgroup records s_memtime at phase boundaries
+#endif
+#if NARROW_STAMPS
+#define P3_STAMP(a, i)                                                                                           \
+    do {                                                                                                         \
+        __builtin_amdgcn_s_waitcnt(0);                                                                           \
+        if ((a).stamps && threadIdx.x == 0)                                                                      \
+            (a).stamps[((uint64_t)(blockIdx.x * gridDim.y + blockIdx.y)) * 32u + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#define P3_STAMP_RT(a, i)                                                                                        \
+    do {                                                                                                         \
+        if ((a).stamps && threadIdx.x == 0)                                                                      \
+            (a).stamps[((uint64_t)(blockIdx.x * gridDim.y + blockIdx.y)) * 32u + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+// every element of v[16] must be computed before the stamp that follows (the compiler otherwise sinks the arithmetic past it)
+#define P3_PIN16(v)                                                              \
+    do {                                                                         \
+        _Pragma("unroll") for (int j__ = 0; j__ < 16; j__++) pin_value((v)[j__]); \
+    } while (0)
+#else
+#define P3_STAMP(a, i) ((void)0)
+#define P3_STAMP_RT(a, i) ((void)0)
+#define P3_PIN16(v) ((void)0)
+#endif
 namespace p3 {
+__device__ __forceinline__ void pin_value(uint32_t& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin_value(uint2& x) { asm volatile("" : "+v"(x.x), "+v"(x.y)); }
+__device__ __forceinline__ void pin_value(double& x) { asm volatile("" : "+v"(x)); }
 
 struct NarrowArgs {
     const uint32_t* src;
@@ -78,6 +106,11 @@ struct NarrowArgs {
     uint32_t mid_handover;        // blocked: the middle kernel re-sorts its results through LDS to store whole lines
     uint32_t cos_per_block;       // K2: cosets one workgroup transforms (grid.y = 2^added / cos_per_block); splitting the
                                   // cosets over workgroups repeats the inverse digit but doubles a thin grid's waves
+    // fp64 kernels (ntt_narrow_f64.hip.h): stage tables as {w, w / P} doubles of CANONICAL values, same layout
+    unsigned long long* stamps;   // NARROW_STAMPS builds: 32 words per workgroup
+    const double2* stage_twd;
+    const double2* stage_twd_fwd;
+    double neg_pm1, pinv, fbias;  // -(P - 1), 1 / P, -1/2 + 2^-33: uniform operands of the fp64 product / floor reduction
     uint32_t blocked;             // W = 2: the two intermediates are stored in 128-byte blocks of
                                   // 4 x 4 (row of one digit, row of the other) pairs, so that the kernel that reads
                                   // them strided touches whole cache lines instead of 32-byte segments
@@ -264,9 +297,36 @@ template <class V>
 __device__ __forceinline__ V ldv(const void* base, uint32_t off) {
     return *reinterpret_cast<const V*>(static_cast<const char*>(base) + off);
 }
+#ifndef NARROW_STORE_WT
+#define NARROW_STORE_WT 0  // 1: write-through stores (global_store ... sc1), 2: non-temporal; A/B: profiles/r03_store_policy_ab.txt
+#endif
 template <class V>
 __device__ __forceinline__ void stv(void* base, uint32_t off, V v) {
-    *reinterpret_cast<V*>(static_cast<char*>(base) + off) = v;
+    V* p = reinterpret_cast<V*>(static_cast<char*>(base) + off);
+#if NARROW_STORE_WT == 1
+    if constexpr (sizeof(V) == 8) {
+        unsigned long long x;
+        __builtin_memcpy(&x, &v, 8);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        uint32_t x;
+        __builtin_memcpy(&x, &v, 4);
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(p), x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#elif NARROW_STORE_WT == 2
+    if constexpr (sizeof(V) == 8) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        u32x2 x;
+        __builtin_memcpy(&x, &v, 8);
+        __builtin_nontemporal_store(x, reinterpret_cast<u32x2*>(p));
+    } else {
+        uint32_t x;
+        __builtin_memcpy(&x, &v, 4);
+        __builtin_nontemporal_store(x, reinterpret_cast<uint32_t*>(p));
+    }
+#else
+    *p = v;
+#endif
 }
 
 // v[j] *= c * phi^(idx(j)), idx(j) = REV ? rev4(j) : j
@@ -297,17 +357,48 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow_inv1_kernel(NarrowAr
     const uint32_t rowstride = a.W << a.n2;                               // words between r1 and r1 + 1
     const uint32_t ld_off = (VW * s + t * rowstride) * 4u;
     V v[16];
+    P3_STAMP_RT(a, 30);
+    if (NARROW_STAMPS && a.stamps && threadIdx.x == 0) a.stamps[((uint64_t)blockIdx.x) * 32u + 0] = __builtin_amdgcn_s_memtime();
 #pragma unroll
     for (uint32_t j = 0; j < 16; j++) v[j] = ldv<V>(a.src + ((uint64_t)j << (B - 4)) * rowstride, ld_off);
     uint32_t w1[15];
     load_round1_twiddles<B>(a.stage_tw, t, w1);
     for (uint32_t i = threadIdx.x; i + 1 < (1u << (B - 4)); i += NTH) twl[i] = a.stage_tw[i];
+    P3_STAMP(a, 1);
     // position (t << 4) | j holds k1 = rev_B(position) = (rev4(j) << (B-4)) | rev(t): twiddle w^-(lo * k1)
     const uint32_t c = two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)lo * rev_bits(t, B - 4));
     const uint32_t phi = two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)lo << (B - 4));
+    P3_STAMP(a, 2);
+#if NARROW_STAMPS
+    {
+        constexpr int A1 = B - 4, A2 = B > 8 ? B - 8 : 0;
+        stage_block_round1(v, w1);
+        P3_PIN16(v);
+        P3_STAMP(a, 8);
+        exchange<LQ, A1, A2, V>(tile, v, t, q);
+        P3_PIN16(v);
+        P3_STAMP(a, 9);
+        stage_block<A2, A1, A2>(v, twl, t);
+        P3_PIN16(v);
+        P3_STAMP(a, 10);
+        if constexpr (B > 8) {
+            exchange<LQ, A2, 0, V>(tile, v, t, q);
+            P3_PIN16(v);
+            P3_STAMP(a, 11);
+            stage_block<0, A2, 0>(v, twl, t);
+        }
+    }
+#else
     dif_rounds<B, LQ>(v, tile, w1, twl, t, q);
+#endif
+    P3_PIN16(v);
+    P3_STAMP(a, 3);
     scale_ladder<true>(v, c, phi);
+    P3_PIN16(v);
+    P3_STAMP(a, 4);
     to_natural<B, LQ>(tile, v, t, q);
+    P3_PIN16(v);
+    P3_STAMP(a, 5);
     // T[(lo * N1 + k1) * W + VW cp], k1 = pt_of<B-4>(t, j): consecutive lanes (cp, then k1) are contiguous for W <= NQ * VW
     if (a.blocked) {
         // W = 2: block (r2 >> 2, k1 >> 2) of 128 bytes holds the row pairs (r2 & 3, k1 & 3), 8 bytes each (cp = column
@@ -315,6 +406,8 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow_inv1_kernel(NarrowAr
         const uint32_t blk_off = ((((lo >> 2) << (B - 2)) + (t >> 2)) * 16u + (lo & 3u) * 4u + (t & 3u)) * 8u + cp * 4u;
 #pragma unroll
         for (uint32_t j = 0; j < 16; j++) stv<V>(a.dst + ((uint64_t)j << (B - 6)) * 32u, blk_off, v[j]);
+        P3_STAMP(a, 6);
+        P3_STAMP_RT(a, 31);
         return;
     }
     const uint32_t st_off = (((lo << B) + t) * a.W + VW * cp) * 4u;

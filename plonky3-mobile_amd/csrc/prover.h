@@ -32,6 +32,9 @@ class FibProver {
     int finish(std::vector<uint8_t>* proof);
     const StageTimes& times() const;
     void reset_times();
+    // proofs so far whose first proof-of-work range held no witness; last_indices = the device's query-index buffer right
+    // after the last such miss, before the search was continued (all zero by construction, tests/test_gpu_prover.py)
+    uint64_t grind_misses(std::vector<uint32_t>* last_indices) const;
 
   private:
     struct Impl;

@@ -580,6 +580,10 @@ struct FibProver::Impl {
     size_t slot_words = 0;
     uint32_t bary_blocks = 0;
     StageTimes times{};
+    // diagnostics of the proof-of-work continuation path (p3hip_fib_prover_grind_miss_probe): how often the first search
+    // range was empty, and the query-index buffer as the device held it when the host learnt of the last miss
+    uint64_t grind_misses = 0;
+    std::vector<uint32_t> miss_qidx;
     ~Impl() {
         for (void* p : allocs) (void)hipFree(p);
         for (auto* h : host_stage) if (h) (void)hipHostFree(h);
@@ -914,6 +918,12 @@ int FibProver::run(uint64_t a, uint64_t b, int slot, int phase, std::vector<uint
             if ((rc = body())) return rc;
             P3_HIP(hipStreamSynchronize(st));
         }
+        // What the query phase left behind on the miss: ts_queries_kernel zeroes the index buffer before it returns, because
+        // query_gather_kernel is already queued behind it and reads that buffer (the round-2 fault: DESIGN.md section 5)
+        s.grind_misses++;
+        s.miss_qidx.assign(nq, 0xdeadbeefu);
+        if (nq) P3_HIP(hipMemcpyAsync(s.miss_qidx.data(), s.qidx, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+        P3_HIP(hipStreamSynchronize(st));
         // continue the search range by range (each 4x the previous one), then redo the query phase
         uint32_t found = 0xffffffffu;
         for (uint64_t base = batch; base < bb::P && found == 0xffffffffu; base += batch) {
@@ -973,6 +983,10 @@ int FibProver::run(uint64_t a, uint64_t b, int slot, int phase, std::vector<uint
 
 const StageTimes& FibProver::times() const { return im->times; }
 void FibProver::reset_times() { im->times = StageTimes{}; }
+uint64_t FibProver::grind_misses(std::vector<uint32_t>* last_indices) const {
+    if (last_indices) *last_indices = im->miss_qidx;
+    return im->grind_misses;
+}
 
 }  // namespace p3
 

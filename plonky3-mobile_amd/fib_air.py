@@ -89,6 +89,15 @@ class FibAirProver:
         names = ["trace_commit", "quotient_commit", "open", "fri_commit_phase", "grind", "queries"]
         return {"prover_" + nm: v / k for nm, v in zip(names, ms)}
 
+    def grind_miss_probe(self):
+        """(misses, indices): how many proofs needed the proof-of-work continuation, and the device's query-index buffer
+        as it stood right after the last miss (numpy uint32; empty before the first miss)."""
+        import numpy as np
+        misses, n = C.c_uint64(), C.c_size_t()
+        buf = (C.c_uint32 * 4096)()
+        _lib.check(_lib.lib().p3hip_fib_prover_grind_miss_probe(self._h, C.byref(misses), buf, 4096, C.byref(n)))
+        return int(misses.value), np.frombuffer(buf, dtype=np.uint32, count=min(n.value, 4096)).copy()
+
     def stage_breakdown(self):
         self.stage_times(reset=True)
         for i in range(3):

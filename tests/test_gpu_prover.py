@@ -235,6 +235,12 @@ def test_grind_search_continues_after_an_empty_first_range(p3, oracle, hash, mon
         witness = int(np.frombuffer(proof[-4:], np.uint32)[0])
         hit_continuation |= int(oracle.from_monty(np.array([witness]))[0]) >= 256
     assert hit_continuation, "no instance needed the continuation path: pick other instances"
+    # Round 2's GPU fault lived here: on a miss ts_queries_kernel returned before it had written the query indices, and
+    # query_gather_kernel — queued behind it unconditionally — indexed the trees with whatever the arena held.  Pinned: a
+    # proof that DID sample indices ran first (a = 0 ... leave non-zero indices in the buffer), and after every later miss
+    # the buffer the gather read is all zero.
+    misses, idx = pr.grind_miss_probe()
+    assert misses >= 1 and len(idx) == gfp.num_queries and not idx.any(), (misses, idx)
     # the same with two proofs in flight: when the older one needs the continuation its arena has been reused by the
     # newer one, so finish() runs it again from the start before continuing the search
     pr.enqueue(0, 1)

@@ -32,6 +32,17 @@ for hash_name, kind in (("poseidon2", o.HASH_POSEIDON2), ("keccak", o.HASH_KECCA
     pr = p3.FibAirProver(13, params=gfp, hash=hash_name)
     assert pr.prove(2, 3) == o.prove_fib_air(2, 3, 13, ofp, hash=kind), hash_name
     pr.close()
+# the narrow three-launch coset LDE (2^16 rows and up) in whichever arithmetic the environment selects: integer or fp64
+# butterflies (P3HIP_NTT_NARROW_F64), column pairs or single columns, one or two LDS tiles
+dft = p3.GpuDft.with_backend(p3.BackendKind.Hip)
+shapes = [(16, 2, 1), (17, 4, 2), (18, 8, 1), (19, 2, 3), (20, 2, 1), (21, 2, 1), (22, 4, 1)]
+if os.environ.get("P3HIP_VARIANT_BIG_LDE") == "1":
+    shapes.append((23, 2, 1))  # 12-stage digits
+for log_h, w, ab in shapes:
+    x = rng.integers(0, P, (1 << log_h, w), dtype=np.uint32)
+    got = p3.host_u32(dft.coset_lde_batch(p3.dev_u32(x), ab, p3.GENERATOR_MONTY, bit_reversed_out=True))
+    assert np.array_equal(got, o.coset_lde_batch(x, ab, p3.GENERATOR_MONTY, True)), ("lde", log_h, w, ab)
+    del got
 hp = p3.FibAirProver(9, params=p3.FriParameters(1, 0, 8, 4), hash="keccak", hiding=True, seed=1)
 assert hp.prove(0, 1) == o.prove_fib_air_hiding(0, 1, 9, o.FriParams(1, 0, 8, 4), hash=o.HASH_KECCAK, seed=1)
 hp.close()

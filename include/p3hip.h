@@ -268,6 +268,25 @@ int p3hip_fib_batch_submit(p3hip_fib_batch_t *batch, size_t n, const uint64_t *a
 int p3hip_fib_batch_collect(p3hip_fib_batch_t *batch, uint64_t ticket, const uint8_t **proofs_out, size_t *lens_out);
 void p3hip_fib_batch_destroy(p3hip_fib_batch_t *batch);
 
+/* ---- The reference's report-returning entry points (native/src/lib.rs:37-131 call fib_air::run_fib_air_zk /
+ * fib_air::run_dft_benchmark and hand the returned String to Java).  Both write a NUL-terminated text of at most cap - 1 bytes
+ * to out and return the length of the WHOLE text (snprintf convention); they never fail by status: a failure is text that
+ * contains "failed", as in the JNI wrappers (lib.rs:48,104), and a message waiting in the error mailbox is appended as
+ * "\nHIP error: ..." (lib.rs:62-65 appends "\nVulkan error: ..."). ---- */
+/* run_fib_air_zk (native/src/fib_air.rs:27-75): the reference's own instance and configuration — n = 8, x = 21, Keccak hashes,
+ * MerkleTreeHidingMmcs + HidingFriPcs seeded with 1, create_test_fri_params(_, 2) — proved on the device and verified on the
+ * host: "fib_air zk ok (n=8, x=21)" (fib_air.rs:74) or "fib_air zk failed: <check>".  Honours the selector: with a backend other
+ * than "hip" selected nothing is run and the text says so (fib_air.rs:60 hard-codes Vulkan; see integration/native/src/fib_air.rs.patch). */
+int p3hip_run_fib_air_zk(char *out, size_t cap);
+/* The CPU column of the benchmark is the caller's: the reference times Plonky3's Radix2DitParallel (fib_air.rs:101,137-141),
+ * which libp3hip does not contain (no CPU path in the product).  Returns 0 on success; Montgomery words, natural row order. */
+typedef int (*p3hip_cpu_dft_fn)(void *user, const uint32_t *in, uint32_t *out, size_t height, size_t width);
+/* run_dft_benchmark (native/src/fib_air.rs:98-222): the reference's 11 shapes, warmup 1, repeats 10, batches of 4; per shape
+ * avg/median/p95 of hip_e2e (host matrix in and out), hip_e2e_batched (4 transforms per synchronisation) and hip_kernel (device
+ * resident, HIP events), the speedups over the caller's CPU transform and the reference's equality check (fib_air.rs:193-196:
+ * "dft benchmark failed: dft benchmark mismatch at h=.., w=.."); cpu_dft == NULL leaves the CPU column and the check out. */
+int p3hip_run_dft_benchmark(p3hip_cpu_dft_fn cpu_dft, void *user, char *out, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -221,4 +221,18 @@ inline std::string run_fib_air(unsigned log_n = 3, uint64_t a = 0, uint64_t b = 
     return "fib_air ok (n=" + std::to_string(n) + ", x=" + std::to_string(x) + ")";
 }
 
+// The String of the reference's runFibAirZk() (lib.rs:37-83) from the library: its own instance and configuration
+// (n = 8, x = 21, Keccak hashes, hiding MMCS + PCS, seed 1) on the backend the selector names.  Never throws: failures are text.
+inline std::string run_fib_air_zk_report() {
+    std::string buf(1024, '\0');
+    p3hip_run_fib_air_zk(&buf[0], buf.size());
+    return std::string(buf.c_str());
+}
+// The String of runDftBenchmark() (lib.rs:86-131); cpu_dft supplies the CPU column (Radix2DitParallel in the Rust shim).
+inline std::string run_dft_benchmark_report(p3hip_cpu_dft_fn cpu_dft = nullptr, void* user = nullptr) {
+    std::string buf(1 << 14, '\0');
+    p3hip_run_dft_benchmark(cpu_dft, user, &buf[0], buf.size());
+    return std::string(buf.c_str());
+}
+
 }  // namespace p3hip

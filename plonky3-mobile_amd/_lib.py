@@ -67,6 +67,8 @@ _SIGS = {
     "p3hip_fib_prover_enqueue": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64]),
     "p3hip_fib_prover_finish": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]),
     "p3hip_fib_prover_destroy": (None, [C.c_void_p]),
+    "p3hip_run_fib_air_zk": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "p3hip_run_dft_benchmark": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]),
     "p3hip_fib_prover_grind_miss_probe": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_size_t,
                                                     C.POINTER(C.c_size_t)]),
     "p3hip_fib_prover_create_hiding": (C.c_int, [C.c_int, C.c_uint, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),

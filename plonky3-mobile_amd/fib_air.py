@@ -247,6 +247,37 @@ def run_fib_air(log_n=3, a=0, b=1, params=None, hash="poseidon2", hiding=False, 
     return "fib_air %sok (n=%d, x=%d)" % ("zk " if hiding else "", n, x)
 
 
+def run_fib_air_zk_report():
+    """p3hip_run_fib_air_zk: the String the reference's runFibAirZk() hands to Java (lib.rs:37-83), produced by the library
+    itself — the reference's own instance and configuration on whatever backend the selector names."""
+    buf = C.create_string_buffer(1024)
+    _lib.lib().p3hip_run_fib_air_zk(buf, len(buf))
+    return buf.value.decode()
+
+
+CPU_DFT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_size_t, C.c_size_t)
+
+
+def run_dft_benchmark_report(cpu_dft=None):
+    """p3hip_run_dft_benchmark: the String of runDftBenchmark() (lib.rs:86-131) from the library; `cpu_dft` (matrix -> matrix
+    on numpy uint32, e.g. the test oracle) supplies the CPU column and the equality check through the C callback the Rust shim
+    would fill with Radix2DitParallel."""
+    import numpy as np
+    cb = None
+    if cpu_dft is not None:
+        def _cb(_user, pin, pout, h, w):
+            try:
+                x = np.ctypeslib.as_array(pin, shape=(h, w)).copy()
+                np.ctypeslib.as_array(pout, shape=(h, w))[:] = cpu_dft(x)
+                return 0
+            except Exception:  # never raise through the C boundary
+                return 1
+        cb = CPU_DFT_FN(_cb)
+    buf = C.create_string_buffer(1 << 14)
+    _lib.lib().p3hip_run_dft_benchmark(C.cast(cb, C.c_void_p) if cb else None, None, buf, len(buf))
+    return buf.value.decode()
+
+
 class DeviceRng:
     """rand 0.9.2 `SmallRng::seed_from_u64(seed)` as a device-resident stream of BabyBear elements (rng.hip)."""
 

@@ -160,3 +160,20 @@ def test_product_hiding_verifier_accepts_oracle_proofs_and_rejects_tampering(p3,
                 bad[pos] = (int(bad[pos]) + 1) % 0x78000001
                 with pytest.raises(p3.P3HipError):
                     p3.verify_fib_air(bad.tobytes(), 2, 3, x, log_n, gfp, hash=hash, hiding=True)
+
+
+def test_report_entry_points_honour_the_selector_without_a_gpu(p3):
+    """p3hip_run_fib_air_zk stands for fib_air::run_fib_air_zk behind lib.rs:37-83: a String, never a status.  With a backend
+    other than hip selected it runs nothing and says so (the reference hard-codes Vulkan at fib_air.rs:60; the drop-in does not
+    override the selector); without a GPU the hip arm reports a failure as text."""
+    p3.set_backend_kind_from_str("cpu")
+    try:
+        text = p3.run_fib_air_zk_report()
+        assert text.startswith("fib_air zk failed: backend 'cpu' is selected")
+    finally:
+        p3.set_backend_kind_from_str("hip")
+    import torch
+    if not torch.cuda.is_available():
+        assert p3.run_fib_air_zk_report().startswith("fib_air zk failed: ")
+        assert p3.run_dft_benchmark_report().startswith("dft benchmark failed: HIP unavailable")
+        p3.take_last_error()

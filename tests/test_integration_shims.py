@@ -45,7 +45,7 @@ def test_rust_shims_bind_the_declared_c_abi():
                 seen.add(name)
     # the shims cover the boundary the reference needs: the DFT entry, the LDE, the MMCS and the diagnostics
     for must in ("p3hip_dft_batch_bb31", "p3hip_coset_lde_batch_bb31", "p3hip_mmcs_commit_hash", "p3hip_mmcs_open_batch",
-                 "p3hip_mmcs_free", "p3hip_take_last_error", "p3hip_is_available"):
+                 "p3hip_mmcs_free", "p3hip_take_last_error", "p3hip_is_available", "p3hip_run_fib_air_zk", "p3hip_run_dft_benchmark"):
         assert must in seen, must
 
 
@@ -66,3 +66,20 @@ def test_selector_patch_follows_the_reference_enum():
         assert needle in patch, needle
     hdr = open(os.path.join(ROOT, "include", "p3hip.h")).read()
     assert "#define P3HIP_BACKEND_HIP 4" in hdr
+
+
+def test_fib_air_patch_makes_the_prover_honour_the_selector():
+    """Round 2's shim set left native/src/fib_air.rs untouched: line 60 hard-codes Vulkan, so setBackend("hip") +
+    runFibAirZk() still ran Vulkan.  The patch must remove exactly that line, route both report functions through
+    hip_front_end.rs when the selector says hip, and offer the hiding MMCS swap."""
+    patch = open(os.path.join(INTEG, "native", "src", "fib_air.rs.patch")).read()
+    ref_line = "let dft = GpuDft::<Val>::with_backend(BackendKind::Vulkan);"
+    assert "-    " + ref_line in patch and "+    let dft = GpuDft::<Val>::default();" in patch
+    for needle in ("run_fib_air_zk_hip()", "run_dft_benchmark_hip()", "BackendKind::Hip", "HipKeccakHidingMmcs<FieldHash, MyCompress>",
+                   "ValHidingMmcs::new(field_hash, compress, 1)", "PCIe-bound"):
+        assert needle in patch, needle
+    front = open(os.path.join(INTEG, "native", "src", "hip_front_end.rs")).read()
+    for needle in ("pub fn run_fib_air_zk_hip() -> Result<String, String>", "pub fn run_dft_benchmark_hip() -> Result<String, String>",
+                   "Radix2DitParallel", 'strip_prefix(prefix)'):
+        assert needle in front, needle
+    assert "mod hip_front_end;" in open(os.path.join(INTEG, "native", "src", "lib.rs.patch")).read()

@@ -98,6 +98,12 @@ int p3hip_coset_dft_batch_bb31_dev(const uint32_t *d_in, uint32_t *d_out, size_t
 int p3hip_coset_lde_batch_bb31_dev(const uint32_t *d_in, uint32_t *d_out, size_t height, size_t width,
                                    unsigned added_bits, uint32_t shift_monty, int bit_reversed_out,
                                    void *stream);
+/* The same extension when the caller already holds COEFFICIENTS (natural order, `height` rows = the degree bound) instead of
+ * evaluations: rows of d_out = evaluations over shift*<g_{height << added_bits}> in bit-reversed order, i.e.
+ * TwoAdicSubgroupDft::coset_dft_batch of the zero-padded coefficient matrix followed by bit_reverse_rows, without transforming
+ * to the subgroup and back (HidingFriPcs commits its blinded quotient chunks from coefficients, fib_air.rs:64-65). */
+int p3hip_coset_lde_from_coeffs_bb31_dev(const uint32_t *d_coeffs, uint32_t *d_out, size_t height, size_t width,
+                                         unsigned added_bits, uint32_t shift_monty, void *stream);
 /* write_bit_reversed_rows_u32 (backend_vulkan.rs:1005-1026) on device */
 int p3hip_bit_reverse_rows_dev(const uint32_t *d_in, uint32_t *d_out, size_t height, size_t width, void *stream);
 

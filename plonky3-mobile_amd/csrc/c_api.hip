@@ -232,6 +232,21 @@ int p3hip_coset_lde_batch_bb31_dev(const uint32_t* in, uint32_t* out, size_t h, 
                                    uint32_t shift, int br_out, void* stream) {
     return dft_dev(OP_COSET_LDE, in, out, h, w, added_bits, shift, br_out, (hipStream_t)stream);
 }
+int p3hip_coset_lde_from_coeffs_bb31_dev(const uint32_t* coeffs, uint32_t* out, size_t h, size_t w, unsigned added_bits,
+                                         uint32_t shift, void* stream) {
+    return guarded([&]() -> int {
+        if (h == 0 || w == 0) return OK;
+        if (!coeffs || !out || coeffs == out) return fail(ERR_BAD_ARG, "coset_lde_from_coeffs: null or aliased pointers");
+        if (w > 0xffffffffull) return fail(ERR_BAD_ARG, "width too large");
+        if (shift >= bb::P) return fail(ERR_BAD_ARG, "shift is not a reduced Montgomery word");
+        Context* cx;
+        int rc = get_context(&cx);
+        if (rc) return rc;
+        hipStream_t st = (hipStream_t)stream;
+        if ((rc = cx->ws(st, 2).reserve(h * w * 4))) return rc;
+        return ntt_coset_lde_from_coeffs(*cx, st, coeffs, out, cx->ws(st, 2).as<uint32_t>(), h, (uint32_t)w, added_bits, shift);
+    });
+}
 int p3hip_bit_reverse_rows_dev(const uint32_t* in, uint32_t* out, size_t h, size_t w, void* stream) {
     return guarded([&]() -> int {
         if (h == 0 || w == 0) return OK;

@@ -110,6 +110,11 @@ int ntt_dft(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* dst,
 // (height << added_bits) x width evaluations over shift*<g>, natural or bit-reversed row order.
 int ntt_coset_lde(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* dst, uint64_t height,
                   uint32_t width, uint32_t added_bits, uint32_t shift_monty, bool bit_reversed_out);
+// The same LDE when the caller already holds the columns' COEFFICIENTS (natural order, `height` rows = degree bound):
+// evaluations over shift*<g_{height << added_bits}> in bit-reversed row order, without the inverse transform.  `scratch`
+// (height x width words) is used only by shapes outside the narrow plan.
+int ntt_coset_lde_from_coeffs(Context& cx, hipStream_t stream, const uint32_t* coeffs, uint32_t* dst, uint32_t* scratch,
+                              uint64_t height, uint32_t width, uint32_t added_bits, uint32_t shift_monty);
 // coset_dft: coefficients (natural order) -> evaluations over shift*<g> (natural order).
 int ntt_coset_dft(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* dst, uint64_t height,
                   uint32_t width, uint32_t shift_monty);

@@ -903,14 +903,17 @@ int launch_narrow64(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32
 }
 
 // Narrow-matrix coset LDE in three launches (ntt_narrow.hip.h).  Returns 1 when the shape is not covered.
+// from_coeffs: src holds the COEFFICIENTS of the columns (natural order, 2^n rows) instead of evaluations over the subgroup:
+// K1 and the inverse half of K2 are skipped (two launches; the hiding prover's blinded quotient chunks arrive that way).
 int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* dst, uint32_t n, uint32_t added, uint32_t W,
-               uint32_t shift, bool bit_reversed_out) {
+               uint32_t shift, bool bit_reversed_out, bool from_coeffs = false) {
     static int enabled = [] { const char* e = getenv("P3HIP_NTT_NARROW"); return e ? atoi(e) : 1; }();
     static uint32_t n_min = [] { const char* e = getenv("P3HIP_NTT_NARROW_MIN"); return e ? (uint32_t)atoi(e) : 16u; }();
     if (!enabled || !bit_reversed_out || added < 1 || added > 3) return 1;
     static uint32_t w_max = [] { const char* e = getenv("P3HIP_NTT_NARROW_WMAX"); return e ? (uint32_t)atoi(e) : 16u; }();
     // 32-byte row segments per tile: faster than the general plans up to W = 16 (1.3-2.1x), level from W = 32 on
-    if (W < 2 || W > w_max || !is_pow2(W)) return 1;
+    // W = 6 (the hiding prover's randomized trace, fib_air.rs:65: 2 columns + 4 random codewords): three column pairs per row
+    if (W < 2 || W > w_max || !(is_pow2(W) || W == 6)) return 1;
     if (n < n_min || n < 16 || n > 24) return 1;
     if ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 7u) return 1;  // 8-byte accesses
     const uint32_t n1 = (n + 1) / 2, n2 = n - n1;
@@ -928,7 +931,8 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     static int use_blocked = [] { const char* e = getenv("P3HIP_NTT_NARROW_BLOCKED"); return e ? atoi(e) : 1; }();
     static int use_handover = [] { const char* e = getenv("P3HIP_NTT_NARROW_HANDOVER"); return e ? atoi(e) : 0; }();
     // blocked intermediates need tiles of 4 rows in all three kernels (32-byte tile rows: digits below 12 stages)
-    a.blocked = use_blocked && !NARROW_MID_SEQ && W == 2 && n1 < 12 && n2 < 12;
+    a.blocked = use_blocked && !NARROW_MID_SEQ && W == 2 && n1 < 12 && n2 < 12 && !from_coeffs;
+    a.from_coeffs = from_coeffs;
     a.mid_handover = use_handover;
     a.n = n; a.n1 = n1; a.n2 = n2; a.W = W; a.added = added;
     TwoLevelTable ti, tf;
@@ -936,11 +940,12 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     if ((rc = cx.get_root_table(stream, n, false, &tf))) return rc;
     auto geometry = [&](int k, uint32_t b, uint64_t rows) -> uint32_t {  // sets wsl / xcd_remap, returns the tile count
         const uint32_t slots_per_row = W / vw[k];
-        a.wsl = log2u(slots_per_row);
+        a.spr = slots_per_row;
+        a.wsl = is_pow2(slots_per_row) ? log2u(slots_per_row) : 0xffffffffu;
         const uint32_t lq = narrow_lq(b, vw[k]);
         const uint32_t tiles = (uint32_t)((rows * slots_per_row) >> lq);
         const uint32_t group = 8u << ((vw[k] == 2 ? 4 : 5) - lq);  // tiles per 128-byte line x 8 XCDs
-        a.xcd_remap = k != 2 && tiles % group == 0;
+        a.xcd_remap = k != 2 && tiles % group == 0 && is_pow2(slots_per_row);
         return tiles;
     };
     // K1
@@ -969,7 +974,8 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
         P3_HIP(hipMemsetAsync(a.stamps, 0, (size_t)tiles * 32 * 8, stream));
     }
 #endif
-    if ((rc = f64(0, n1) ? launch_narrow64<1>(cx, stream, a, n1, tiles, vw[0]) : launch_narrow<1>(cx, stream, a, n1, tiles, vw[0]))) return rc;
+    if (!from_coeffs)
+        if ((rc = f64(0, n1) ? launch_narrow64<1>(cx, stream, a, n1, tiles, vw[0]) : launch_narrow<1>(cx, stream, a, n1, tiles, vw[0]))) return rc;
 #if NARROW_STAMPS
     if (a.stamps) {
         std::vector<unsigned long long> h((size_t)tiles * 32);
@@ -985,11 +991,11 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     }
 #endif
     // K2
-    a.src = T; a.dst = dst;
+    a.src = from_coeffs ? src : T; a.dst = dst;
     a.stage_tw = cx.tile_tw[1]; a.stage_tw_fwd = cx.tile_tw[0];
     a.stage_twd = cx.tile_twd[1]; a.stage_twd_fwd = cx.tile_twd[0];
     a.twf_lo = tf.lo; a.twf_hi = tf.hi; a.twf_T = tf.T;
-    const uint32_t hinv = bb::inv(bb::to_monty((uint32_t)N));
+    const uint32_t hinv = from_coeffs ? bb::ONE : bb::inv(bb::to_monty((uint32_t)N));  // the 1 / N of the inverse transform
     const uint32_t g = bb::two_adic_generator(n + added);
     uint32_t base = shift;
     for (uint32_t j = 0; j < (1u << added); j++) {
@@ -1060,6 +1066,21 @@ int ntt_coset_dft(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t
     }
     if (src == dst) return fail(ERR_BAD_ARG, "coset_dft: in-place not supported");
     return run_dif(cx, stream, src, height, dst, n, width, false, &sc, shift, true);
+}
+
+int ntt_coset_lde_from_coeffs(Context& cx, hipStream_t stream, const uint32_t* coeffs, uint32_t* dst, uint32_t* scratch,
+                              uint64_t height, uint32_t width, uint32_t added_bits, uint32_t shift) {
+    if (!height || !width) return OK;
+    if (!is_pow2(height)) return fail(ERR_BAD_ARG, "hip backend requires power-of-two height, got " + std::to_string(height));
+    const uint32_t n = log2u(height);
+    if (n + added_bits > bb::TWO_ADICITY) return fail(ERR_BAD_ARG, "LDE height exceeds BabyBear two-adicity");
+    { int rcs = cx.reserve_scale_slots(8); if (rcs) return rcs; }
+    int rcn = lde_narrow(cx, stream, coeffs, dst, n, added_bits, width, shift, true, true);
+    if (rcn != 1) return rcn;
+    // shapes outside the narrow plan: evaluations over the subgroup first, then the ordinary LDE
+    int rc = ntt_dft(cx, stream, coeffs, scratch, height, width, false);
+    if (rc) return rc;
+    return ntt_coset_lde(cx, stream, scratch, dst, height, width, added_bits, shift, true);
 }
 
 int ntt_coset_lde(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* dst, uint64_t height,

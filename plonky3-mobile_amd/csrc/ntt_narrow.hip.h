@@ -88,7 +88,10 @@ __device__ __forceinline__ void pin_value(double& x) { asm volatile("" : "+v"(x)
 struct NarrowArgs {
     const uint32_t* src;
     uint32_t* dst;
-    uint32_t n, n1, n2, W, wsl;   // wsl = log2(W / VW): slots (lane vectors of VW words) per row
+    uint32_t n, n1, n2, W, wsl;   // wsl = log2(W / VW): slots (lane vectors of VW words) per row; 0xffffffff when that is not a
+                                  // power of two (W = 6, 12: the hiding prover's trace), then spr is divided by
+    uint32_t spr;                 // slots per row = W / VW
+    uint32_t from_coeffs;         // K2: src holds COEFFICIENTS (natural order): no inverse digit, no K1 before it
     uint32_t added;
     const uint32_t* stage_tw;     // this kernel's direction: stage u at offset 2^u - 1 (reference layout, 12 stages)
     const uint32_t* stage_tw_fwd; // K2: forward table
@@ -341,6 +344,12 @@ __device__ __forceinline__ void scale_ladder(V (&v)[16], uint32_t c, uint32_t ph
 
 }  // namespace narrow
 
+// slot index -> (row group, column slot)
+__device__ __forceinline__ uint32_t slot_row(const NarrowArgs& a, uint32_t s) { return a.wsl != 0xffffffffu ? s >> a.wsl : s / a.spr; }
+__device__ __forceinline__ uint32_t slot_col(const NarrowArgs& a, uint32_t s, uint32_t row) {
+    return a.wsl != 0xffffffffu ? s & ((1u << a.wsl) - 1u) : s - row * a.spr;
+}
+
 // K1: first inverse digit (the high n1 bits of the row index), transposed store.
 template <int B, int LQ, int VW>
 __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow_inv1_kernel(NarrowArgs a) {
@@ -353,7 +362,7 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow_inv1_kernel(NarrowAr
     uint32_t* twl = smem + (NT * VW * lds_rows(B) << LQ);                  // stages below B-4: 2^(B-4) - 1 words
     const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> LQ;
     const uint32_t s = tile_of_block<LQ, VW>(blockIdx.x, a.xcd_remap) * NQ + q;  // slot (VW words) within a row group of N2 rows
-    const uint32_t lo = s >> a.wsl, cp = s & ((1u << a.wsl) - 1u);
+    const uint32_t lo = slot_row(a, s), cp = slot_col(a, s, lo);
     const uint32_t rowstride = a.W << a.n2;                               // words between r1 and r1 + 1
     const uint32_t ld_off = (VW * s + t * rowstride) * 4u;
     V v[16];
@@ -436,7 +445,7 @@ narrow_mid_kernel(NarrowArgs a) {
     uint32_t* twl_f = twl_i + (1u << (B - 4));                // forward stages below B-4
     const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> LQ;
     const uint32_t s = tile_of_block<LQ, VW>(blockIdx.x, a.xcd_remap) * NQ + q;  // slot within a group of N1 rows
-    const uint32_t k1 = s >> a.wsl;
+    const uint32_t k1 = slot_row(a, s);
     const uint32_t rowstride = a.W << a.n1;
     const uint32_t ld_off = (VW * s + t * rowstride) * 4u, st_off = (VW * s + (t << 4) * rowstride) * 4u;
     const bool blocked = a.blocked;
@@ -453,7 +462,7 @@ narrow_mid_kernel(NarrowArgs a) {
         load_round1_twiddles<B>(a.stage_tw, t, w1);
         for (uint32_t i = threadIdx.x; i + 1 < (1u << (B - 4)); i += NTH) twl_i[i] = a.stage_tw[i];
         for (uint32_t i = threadIdx.x; i + 1 < (1u << (B - 4)); i += NTH) twl_f[i] = a.stage_tw_fwd[i];
-        dif_rounds<B, LQ>(c, tile, w1, twl_i, t, q);
+        if (!a.from_coeffs) dif_rounds<B, LQ>(c, tile, w1, twl_i, t, q);
     }
     // forward twiddle w^(k1 * m1), m1 = rev_B(position): the same for every coset
     const uint32_t c0 = two_level(a.twf_lo, a.twf_hi, a.twf_T, (uint64_t)k1 * rev_bits(t, B - 4));
@@ -461,7 +470,8 @@ narrow_mid_kernel(NarrowArgs a) {
     const uint64_t kbase = (uint64_t)k1 + ((uint64_t)t << a.n1);
     const uint32_t cos0 = blockIdx.y * a.cos_per_block, ncos = cos0 + a.cos_per_block;  // this workgroup's cosets
     uint32_t sc_next = two_level(a.sc_lo[cos0], a.sc_hi[cos0], a.sc_T, kbase);
-    to_natural<B, LQ>(tile, c, t, q);  // c[j] = coefficient k = k1 + N1 * k2, k2 = pt_of<B-4>(t, j) = (j << (B-4)) | t
+    // c[j] = coefficient k = k1 + N1 * k2, k2 = pt_of<B-4>(t, j) = (j << (B-4)) | t (what a coefficient matrix's rows already are)
+    if (!a.from_coeffs) to_natural<B, LQ>(tile, c, t, q);
     if constexpr (SEQ) {
         __syncthreads();  // the 32-bit tiles below alias the pair tile: its last reads (to_natural) are done
         Tiles<uint32_t, true> t32{smem, smem + (lds_rows(B) << LQ)};
@@ -558,7 +568,7 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow_fwd2_kernel(NarrowAr
     uint32_t* twl = smem + (NT * VW * lds_rows(B) << LQ);
     const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> LQ;
     const uint32_t s = blockIdx.x * NQ + q;
-    const uint32_t blk0 = (blockIdx.x * NQ) >> a.wsl, blk = s >> a.wsl, cp = s & ((1u << a.wsl) - 1u);
+    const uint32_t blk0 = slot_row(a, blockIdx.x * NQ), blk = slot_row(a, s), cp = slot_col(a, s, blk);
     uint32_t* p = a.dst + ((uint64_t)blk0 << B) * a.W;                    // uniform: the workgroup's first block
     const uint32_t off = ((((blk - blk0) << B) + t) * a.W + VW * cp) * 4u;
     V v[16];

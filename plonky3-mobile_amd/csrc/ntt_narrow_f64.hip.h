@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow64_inv1_kernel(Narrow
     const Uni un{a.neg_pm1, a.pinv, a.fbias};
     const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> LQ;
     const uint32_t s = tile_of_block<LQ, VW>(blockIdx.x, a.xcd_remap) * NQ + q;
-    const uint32_t lo = s >> a.wsl, cp = s & ((1u << a.wsl) - 1u);
+    const uint32_t lo = slot_row(a, s), cp = slot_col(a, s, lo);
     const uint32_t rowstride = a.W << a.n2;
     const uint32_t ld_off = (VW * s + t * rowstride) * 4u;
     DV<VW> v[16];
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow64_mid_kernel(NarrowA
     const Uni un{a.neg_pm1, a.pinv, a.fbias};
     const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> LQ;
     const uint32_t s = tile_of_block<LQ, VW>(blockIdx.x, a.xcd_remap) * NQ + q;
-    const uint32_t k1 = s >> a.wsl;
+    const uint32_t k1 = slot_row(a, s);
     const uint32_t rowstride = a.W << a.n1;
     const uint32_t ld_off = (VW * s + t * rowstride) * 4u, st_off = (VW * s + (t << 4) * rowstride) * 4u;
     const bool blocked = a.blocked;
@@ -317,14 +317,14 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow64_mid_kernel(NarrowA
         load_round1_twiddles<B>(a.stage_twd, t, w1);
         for (uint32_t i = threadIdx.x; i + 1 < (1u << (B - 4)); i += NTH) twl_i[i] = a.stage_twd[i];
         for (uint32_t i = threadIdx.x; i + 1 < (1u << (B - 4)); i += NTH) twl_f[i] = a.stage_twd_fwd[i];
-        dif_rounds<B, LQ>(c, tile, w1, twl_i, t, q, mk, un);
+        if (!a.from_coeffs) dif_rounds<B, LQ>(c, tile, w1, twl_i, t, q, mk, un);
     }
     const double c0 = canon(two_level(a.twf_lo, a.twf_hi, a.twf_T, (uint64_t)k1 * rev_bits(t, B - 4)));
     const double phi0 = canon(two_level(a.twf_lo, a.twf_hi, a.twf_T, (uint64_t)k1 << (B - 4)));
     const uint64_t kbase = (uint64_t)k1 + ((uint64_t)t << a.n1);
     const uint32_t cos0 = blockIdx.y * a.cos_per_block, ncos = cos0 + a.cos_per_block;
     uint32_t sc_next = two_level(a.sc_lo[cos0], a.sc_hi[cos0], a.sc_T, kbase);
-    to_natural<B, LQ>(tile, c, t, q);  // c[j] = coefficient k = k1 + N1 * k2, k2 = (j << (B-4)) | t
+    if (!a.from_coeffs) to_natural<B, LQ>(tile, c, t, q);  // c[j] = coefficient k = k1 + N1 * k2, k2 = (j << (B-4)) | t
     double pw2[16];
     if constexpr (!LEAN) power_ladder16(c0, phi0, pw2, mk, un);
     for (uint32_t jc = cos0; jc < ncos; jc++) {
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow64_fwd2_kernel(Narrow
     const Uni un{a.neg_pm1, a.pinv, a.fbias};
     const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> LQ;
     const uint32_t s = blockIdx.x * NQ + q;
-    const uint32_t blk0 = (blockIdx.x * NQ) >> a.wsl, blk = s >> a.wsl, cp = s & ((1u << a.wsl) - 1u);
+    const uint32_t blk0 = slot_row(a, blockIdx.x * NQ), blk = slot_row(a, s), cp = slot_col(a, s, blk);
     uint32_t* p = a.dst + ((uint64_t)blk0 << B) * a.W;
     const uint32_t off = ((((blk - blk0) << B) + t) * a.W + VW * cp) * 4u;
     DV<VW> v[16];

@@ -141,6 +141,17 @@ class GpuDft:
                          C.c_int(int(bool(bit_reversed_out))))
 
 
+def coset_lde_from_coeffs(coeffs, added_bits, shift_monty):
+    """Device tensor of COEFFICIENTS (h x w, natural order) -> evaluations over shift*<g_{h << added_bits}>, bit-reversed rows
+    (= coset_dft_batch of the zero-padded matrix + bit_reverse_rows; p3hip_coset_lde_from_coeffs_bb31_dev)."""
+    import torch
+    h, w = coeffs.shape
+    out = torch.empty((h << added_bits, w), dtype=torch.int32, device=coeffs.device)
+    _lib.check(_lib.lib().p3hip_coset_lde_from_coeffs_bb31_dev(C.c_void_p(coeffs.data_ptr()), C.c_void_p(out.data_ptr()), h, w,
+                                                               C.c_uint(added_bits), C.c_uint32(int(shift_monty)), _stream_ptr()))
+    return out
+
+
 def bit_reverse_rows(t):
     import torch
     out = torch.empty_like(t)

@@ -110,6 +110,30 @@ def test_hiding_headline_size_verifies(p3, oracle):
     pr.close()
 
 
+def test_hiding_bench_size_in_the_reference_configuration(p3, oracle):
+    """bench.py --hash keccak --hiding at its size: 2^20-row trace (randomized to 2^21, LDE 2^22: the W = 6 trace matrix and the
+    chunk LDEs from coefficients go through the narrow plan at this size), Keccak hashes, seed 1.  The oracle's independent
+    verifier accepts the proof for x and rejects it for x + 1; a second proof has the same bytes (the streams restart)."""
+    gfp, ofp = _fp(p3, oracle, 1, 0, 100, 16)
+    pr = p3.FibAirProver(20, params=gfp, hash="keccak", hiding=True, seed=1)
+    proof = pr.prove(0, 1)
+    x = oracle.fib_public_x(0, 1, 1 << 20)
+    assert oracle.verify_fib_air_hiding(proof, 0, 1, x, 20, ofp, hash=oracle.HASH_KECCAK) == 0
+    assert oracle.verify_fib_air_hiding(proof, 0, 1, (x + 1) % 0x78000001, 20, ofp, hash=oracle.HASH_KECCAK) != 0
+    assert pr.prove(0, 1) == proof
+    pr.close()
+
+
+@pytest.mark.parametrize("log_n", [14, 15, 16, 17])
+def test_hiding_proof_bytes_where_the_narrow_plan_takes_over(p3, oracle, log_n):
+    """Byte for byte against the oracle prover at the sizes where the hiding prover's transforms switch plans: the randomized
+    trace (2^(n+1) x 6) and the chunk matrices (from coefficients) enter the narrow plan at 2^16 rows, i.e. log_n = 15."""
+    gfp, ofp = _fp(p3, oracle, 1, 0, 6, 4)
+    pr = p3.FibAirProver(log_n, params=gfp, hash="keccak", hiding=True, seed=1)
+    assert pr.prove(3, 4) == oracle.prove_fib_air_hiding(3, 4, log_n, ofp, hash=oracle.HASH_KECCAK, seed=1)
+    pr.close()
+
+
 @pytest.mark.parametrize("hash", ["poseidon2", "keccak"])
 def test_hiding_mmcs_commit_and_openings(p3, oracle, hash):
     """MerkleTreeHidingMmcs on the device: salts drawn from the MMCS's own stream in input order, leaves m0 || s0 || m1 || s1;

@@ -225,6 +225,30 @@ def test_narrow_three_launch_lde(dft, oracle, p3, log_h, w, ab):
     assert np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("log_h,ab", [(16, 1), (17, 2), (18, 1), (19, 3), (20, 1), (21, 1), (22, 1)])
+def test_narrow_lde_of_six_columns(dft, oracle, p3, log_h, ab):
+    """W = 6 — the hiding prover's randomized trace (2 trace columns + 4 random codewords, fib_air.rs:65) — through the narrow
+    plan: three column pairs (or six single columns) per row, so a tile's slots straddle rows."""
+    rng = np.random.default_rng(6000 + 10 * log_h + ab)
+    x = _rand(rng, 1 << log_h, 6)
+    shift = p3.GENERATOR_MONTY if log_h % 2 == 0 else int(rng.integers(1, P))
+    assert np.array_equal(dft.coset_lde_batch(x, ab, shift, bit_reversed_out=True), oracle.coset_lde_batch(x, ab, shift, True))
+
+
+@pytest.mark.parametrize("log_h,w,ab", [(16, 4, 1), (17, 2, 2), (18, 6, 1), (19, 4, 1), (20, 4, 1), (21, 4, 1), (21, 16, 1), (22, 2, 2),
+                                        (12, 4, 1), (15, 5, 2), (16, 32, 1)])
+def test_coset_lde_from_coefficients(oracle, p3, log_h, w, ab):
+    """p3hip_coset_lde_from_coeffs_bb31_dev: evaluations over shift*<g> of a matrix given by COEFFICIENTS, bit-reversed rows —
+    two launches of the narrow plan (no inverse digits) where it covers the shape, dft + LDE elsewhere (the last three shapes).
+    Oracle: evaluate on the subgroup (dft_batch), then the ordinary coset LDE."""
+    rng = np.random.default_rng(7000 + 100 * log_h + 10 * w + ab)
+    c = _rand(rng, 1 << log_h, w)
+    shift = p3.GENERATOR_MONTY if (log_h + w) % 2 == 0 else int(rng.integers(1, P))
+    exp = oracle.coset_lde_batch(oracle.dft_batch(c), ab, shift, True)
+    got = p3.host_u32(p3.coset_lde_from_coeffs(p3.dev_u32(c), ab, shift))
+    assert np.array_equal(got, exp)
+
+
 def test_raw_u32_plan_entry_like_the_reference_benchmark(p3, oracle):
     """prepare_compute_plan(width, height, 0, log_n) + setup_pipeline_plan(&plan, &[u32]) as the reference's benchmark
     drives them (fib_air.rs:128-134): natural-order Montgomery words in and out."""

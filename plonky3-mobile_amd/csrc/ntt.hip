@@ -931,7 +931,17 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     static int use_blocked = [] { const char* e = getenv("P3HIP_NTT_NARROW_BLOCKED"); return e ? atoi(e) : 1; }();
     static int use_handover = [] { const char* e = getenv("P3HIP_NTT_NARROW_HANDOVER"); return e ? atoi(e) : 0; }();
     // blocked intermediates need tiles of 4 rows in all three kernels (32-byte tile rows: digits below 12 stages)
-    a.blocked = use_blocked && !NARROW_MID_SEQ && W == 2 && n1 < 12 && n2 < 12 && !from_coeffs;
+    // 12-stage digits have 2-row tiles: K3 then owns half of every 128-byte block and can no longer run in place, so K2 writes
+    // the blocked intermediate to a scratch of its own (P3HIP_NTT_NARROW_BLOCKED12=0: row-major intermediates as in round 2)
+    static int use_blocked12 = [] { const char* e = getenv("P3HIP_NTT_NARROW_BLOCKED12"); return e ? atoi(e) : 1; }();
+    const bool twelve = n1 >= 12 || n2 >= 12;
+    a.blocked = use_blocked && !NARROW_MID_SEQ && W == 2 && !from_coeffs && (!twelve || use_blocked12);
+    const bool k3_out_of_place = a.blocked && n1 >= 12;
+    uint32_t* mid = dst;  // K2's output = K3's input
+    if (k3_out_of_place) {
+        if ((rc = cx.ws(stream, 3).reserve((N << added) * W * 4))) return rc;
+        mid = cx.ws(stream, 3).as<uint32_t>();
+    }
     a.from_coeffs = from_coeffs;
     a.mid_handover = use_handover;
     a.n = n; a.n1 = n1; a.n2 = n2; a.W = W; a.added = added;
@@ -991,7 +1001,7 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     }
 #endif
     // K2
-    a.src = from_coeffs ? src : T; a.dst = dst;
+    a.src = from_coeffs ? src : T; a.dst = mid;
     a.stage_tw = cx.tile_tw[1]; a.stage_tw_fwd = cx.tile_tw[0];
     a.stage_twd = cx.tile_twd[1]; a.stage_twd_fwd = cx.tile_twd[0];
     a.twf_lo = tf.lo; a.twf_hi = tf.hi; a.twf_T = tf.T;
@@ -1019,10 +1029,11 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     if ((rc = f64(1, n2) ? launch_narrow64<2>(cx, stream, a, n2, tiles, vw[1], 1u << split_log)
                          : launch_narrow<2>(cx, stream, a, n2, tiles, vw[1], 1u << split_log))) return rc;
     // K3
-    a.src = dst; a.dst = dst;
+    a.src = mid; a.dst = dst;
     a.stage_tw = cx.tile_tw[0];
     a.stage_twd = cx.tile_twd[0];
     tiles = geometry(2, n1, (1ull << added) << n2);
+    a.k3_pairs = k3_out_of_place && vw[2] == 2 && tiles % 16 == 0;
     return f64(2, n1) ? launch_narrow64<3>(cx, stream, a, n1, tiles, vw[2]) : launch_narrow<3>(cx, stream, a, n1, tiles, vw[2]);
 }
 

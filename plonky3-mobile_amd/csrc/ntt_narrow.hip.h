@@ -114,6 +114,8 @@ struct NarrowArgs {
     const double2* stage_twd;
     const double2* stage_twd_fwd;
     double neg_pm1, pinv, fbias;  // -(P - 1), 1 / P, -1/2 + 2^-33: uniform operands of the fp64 product / floor reduction
+    uint32_t k3_pairs;            // K3 with 2-row tiles over blocked input: partner tiles (the two halves of every 128-byte block)
+                                  // go to one XCD; K3 then reads a.src (out of place: in place the partner's half would be overwritten)
     uint32_t blocked;             // W = 2: the two intermediates are stored in 128-byte blocks of
                                   // 4 x 4 (row of one digit, row of the other) pairs, so that the kernel that reads
                                   // them strided touches whole cache lines instead of 32-byte segments
@@ -344,6 +346,13 @@ __device__ __forceinline__ void scale_ladder(V (&v)[16], uint32_t c, uint32_t ph
 
 }  // namespace narrow
 
+// K3 tiles of 2 row blocks over blocked input: blocks b and b + 8 of the grid share an XCD (round-robin dealing), give them the two
+// halves of one group of four row blocks (speed only: the result does not depend on placement)
+__device__ __forceinline__ uint32_t k3_tile_of_block(uint32_t bid, uint32_t pairs) {
+    if (!pairs) return bid;
+    const uint32_t xcd = bid & 7u, s = bid >> 3;
+    return ((s >> 1) << 4) | (xcd << 1) | (s & 1u);
+}
 // slot index -> (row group, column slot)
 __device__ __forceinline__ uint32_t slot_row(const NarrowArgs& a, uint32_t s) { return a.wsl != 0xffffffffu ? s >> a.wsl : s / a.spr; }
 __device__ __forceinline__ uint32_t slot_col(const NarrowArgs& a, uint32_t s, uint32_t row) {
@@ -567,16 +576,21 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow_fwd2_kernel(NarrowAr
     Tiles<V, (NT > 1)> tile{reinterpret_cast<V*>(smem), reinterpret_cast<V*>(smem) + (NT - 1) * (lds_rows(B) << LQ)};
     uint32_t* twl = smem + (NT * VW * lds_rows(B) << LQ);
     const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> LQ;
-    const uint32_t s = blockIdx.x * NQ + q;
-    const uint32_t blk0 = slot_row(a, blockIdx.x * NQ), blk = slot_row(a, s), cp = slot_col(a, s, blk);
+    const uint32_t tile0 = k3_tile_of_block(blockIdx.x, a.k3_pairs);
+    const uint32_t s = tile0 * NQ + q;
+    const uint32_t blk0 = slot_row(a, tile0 * NQ), blk = slot_row(a, s), cp = slot_col(a, s, blk);
     uint32_t* p = a.dst + ((uint64_t)blk0 << B) * a.W;                    // uniform: the workgroup's first block
     const uint32_t off = ((((blk - blk0) << B) + t) * a.W + VW * cp) * 4u;
     V v[16];
     if (a.blocked) {
-        // W = 2: the workgroup's four blocks of 2^B rows arrive as 128-byte blocks (k1 >> 2) of pairs (row block & 3, k1 & 3)
-        const uint32_t blk_off = ((t >> 2) * 16u + (blk - blk0) * 4u + (t & 3u)) * 8u + cp * 4u;
+        // W = 2: a group of four blocks of 2^B rows arrives as 128-byte blocks (k1 >> 2) of pairs (row block & 3, k1 & 3).  With
+        // 32-byte tile rows the workgroup owns the whole group (in place: a.src == a.dst); with 16-byte tile rows (12-stage digits) it
+        // owns two of the four and reads them from a.src, a buffer of its own.
+        const uint32_t g0 = blk0 & ~3u;
+        const uint32_t* ps = a.src + ((uint64_t)g0 << B) * a.W;
+        const uint32_t blk_off = ((t >> 2) * 16u + (blk - g0) * 4u + (t & 3u)) * 8u + cp * 4u;
 #pragma unroll
-        for (uint32_t j = 0; j < 16; j++) v[j] = ldv<V>(p + ((uint64_t)j << (B - 6)) * 32u, blk_off);
+        for (uint32_t j = 0; j < 16; j++) v[j] = ldv<V>(ps + ((uint64_t)j << (B - 6)) * 32u, blk_off);
     } else {
 #pragma unroll
         for (uint32_t j = 0; j < 16; j++) v[j] = ldv<V>(p + ((uint64_t)j << (B - 4)) * a.W, off);

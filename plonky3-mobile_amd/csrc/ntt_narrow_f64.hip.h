@@ -372,15 +372,18 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow64_fwd2_kernel(Narrow
     const Magic mk = pin_magic();
     const Uni un{a.neg_pm1, a.pinv, a.fbias};
     const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> LQ;
-    const uint32_t s = blockIdx.x * NQ + q;
-    const uint32_t blk0 = slot_row(a, blockIdx.x * NQ), blk = slot_row(a, s), cp = slot_col(a, s, blk);
+    const uint32_t tile0 = k3_tile_of_block(blockIdx.x, a.k3_pairs);
+    const uint32_t s = tile0 * NQ + q;
+    const uint32_t blk0 = slot_row(a, tile0 * NQ), blk = slot_row(a, s), cp = slot_col(a, s, blk);
     uint32_t* p = a.dst + ((uint64_t)blk0 << B) * a.W;
     const uint32_t off = ((((blk - blk0) << B) + t) * a.W + VW * cp) * 4u;
     DV<VW> v[16];
     if (a.blocked) {
-        const uint32_t blk_off = ((t >> 2) * 16u + (blk - blk0) * 4u + (t & 3u)) * 8u + cp * 4u;
+        const uint32_t g0 = blk0 & ~3u;  // see narrow_fwd2_kernel: a.src == a.dst unless the tile owns half a group
+        const uint32_t* ps = a.src + ((uint64_t)g0 << B) * a.W;
+        const uint32_t blk_off = ((t >> 2) * 16u + (blk - g0) * 4u + (t & 3u)) * 8u + cp * 4u;
 #pragma unroll
-        for (uint32_t j = 0; j < 16; j++) v[j] = ld_words<VW>(p + ((uint64_t)j << (B - 6)) * 32u, blk_off);
+        for (uint32_t j = 0; j < 16; j++) v[j] = ld_words<VW>(ps + ((uint64_t)j << (B - 6)) * 32u, blk_off);
     } else {
 #pragma unroll
         for (uint32_t j = 0; j < 16; j++) v[j] = ld_words<VW>(p + ((uint64_t)j << (B - 4)) * a.W, off);

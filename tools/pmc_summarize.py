@@ -29,8 +29,9 @@ launches = [{"kernel": k[:60], "fetch_bytes": 2.0 * f * 1024, "write_bytes": w *
 
 def unit(names, which):
     """the `which`-th (from the end) consecutive run of launches whose kernel names start with `names` in order"""
+    # integer and fp64 forms of the three launches count alike ("narrow_inv1_kernel<10" / "narrow64_inv1_kernel<10")
     idx = [i for i in range(len(launches) - len(names) + 1)
-           if all(launches[i + j]["kernel"].startswith(n) for j, n in enumerate(names))]
+           if all(launches[i + j]["kernel"].replace("narrow64_", "narrow_").startswith(n) for j, n in enumerate(names))]
     i = idx[which]
     return launches[i:i + len(names)]
 

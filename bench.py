@@ -445,6 +445,15 @@ def run(args, job, dist, world, rank, local_rank, n_dev, backend, coll_dev, use_
                   "recall; pinned by reference code only for the DFT): self-consistent, upstream parity UNPINNED",
     }
     out.update(job.extra_report())
+    vr = out.get("valu_roofline")
+    if isinstance(vr, dict) and vr.get("permutations_per_proof"):
+        # what the timed region sustained, in the hash kernels' own unit: proofs/s x permutations per proof
+        vr["sustained_gperm_s"] = value * vr["permutations_per_proof"] / 1e9
+        ceiling = vr.get("kernel_ceiling_gperm_s")
+        if ceiling:
+            vr["sustained_frac_of_kernel_ceiling"] = vr["sustained_gperm_s"] / (ceiling * world)
+            vr["kernel_ceiling"] = ("permutations / time of one 2^24 x 2 commit timed in this run (layers of >= 2^20 lanes fill the chip for many "
+                                    "workgroup generations: the hash kernels at their own VALU-bound rate), per GPU")
     if world > 1:
         out["cpu_baseline"] = "omitted for world > 1 (the CPU leg is timed by the N=1 run only)"
     elif stub or args.no_cpu_baseline:

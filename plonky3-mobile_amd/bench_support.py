@@ -138,7 +138,7 @@ class FibAirJob:
         roof = self.lde_roofline(reps=20)
         traffic, src = None, None
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        for name in ("r02_pmc_lde.json", "r01_pmc_lde_v2.json"):
+        for name in ("r03_pmc_lde.json", "r02_pmc_lde.json", "r01_pmc_lde_v2.json"):
             try:
                 with open(os.path.join(root, "profiles", name)) as f:
                     pmc = json.load(f)
@@ -157,50 +157,114 @@ class FibAirJob:
                 "concurrent_gbps": roof.get("concurrent_gbps"), "concurrent_streams": roof.get("concurrent_streams")}
 
     def extra_report(self):
-        out = {"valu_roofline": self.poseidon2_roofline()}
+        out = {"valu_roofline": self.hash_roofline()}
         if not self.hiding:  # the hiding prover keeps no per-stage events
             out["stages_ms"] = self.stage_breakdown()
         return out
 
-    def poseidon2_roofline(self):
-        """The kernels that dominate a proof BY TIME are the Poseidon2 leaf / compression layers (12.6 M permutations per
-        2^20 proof) and they are VALU-bound, which the contract's hbm|mfma roofline cannot express.  achieved = the rate of
-        the kernels the prover really runs (a 2^21 x 2 commit: leaf_hash_f64 + compress_layer_f64 + the small layers);
-        the ceiling is NOT a model: `frac` = VALU-busy cycles / elapsed cycles of those kernels from the committed PMC
-        pass (profiles/r02_pmc_poseidon2.json), so it is <= 1 by construction."""
+    # ---- the hash layers: what a proof spends its time in, and the VALU evidence of the configuration that ran ----
+    def tree_shapes(self):
+        """(rows, words per leaf row) of every Merkle tree one proof commits, in order."""
+        big = self.n << self.log_blowup
+        if self.hiding:  # prover_hiding.hip.inc: randomized trace on 2h rows; leaf rows carry 4 salt words per matrix
+            big <<= 1
+            shapes = [(big, 6 + 4), (big, 4 * (4 + 4)), (big, 8 + 4)]
+            fri_row = 8 + 4
+        else:
+            shapes = [(big, 2), (big, 4)]
+            fri_row = 8
+        log_big = big.bit_length() - 1
+        rounds = log_big - self.params.log_blowup - self.params.log_final_poly_len
+        shapes += [(big >> (r + 1), fri_row) for r in range(rounds)]
+        return shapes
+
+    def permutations_per_proof(self):
+        """Leaf sponge + compression permutations of one proof (the grind and transcript permutations, a few thousand, left out).
+        Poseidon2: rate 8 words; Keccak: 17 u64 = 34 field elements per permutation (fib_air.rs:31-38)."""
+        rate = 34 if self.hash == "keccak" else 8
+        return sum(rows * ((w + rate - 1) // rate) + rows - 1 for rows, w in self.tree_shapes())
+
+    def _pmc_rows(self):
+        """Per-launch counter rows of the hash kernels of THIS hash configuration, from the committed PMC pass."""
         import json
-        n = self.n << self.log_blowup
-        x = torch.randint(0, 0x78000001, (n, 2), dtype=torch.int32, device="cuda")
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        names = (("r03_pmc_keccak.json", "r02_pmc_keccak.json") if self.hash == "keccak"
+                 else ("r03_pmc_poseidon2.json", "r02_pmc_poseidon2.json"))
+        for name in names:
+            try:
+                with open(os.path.join(root, "profiles", name)) as f:
+                    pmc = json.load(f)
+            except Exception:
+                continue
+            if self.hash == "keccak":
+                rows = pmc["kernels"]
+                leaf = [r for r in rows if "keccak_leaf_kernel" in r["kernel"]]
+                comp = [r for r in rows if "keccak_compress_kernel" in r["kernel"]]
+            else:
+                leaf, comp = pmc.get("leaf_hash_f64", []), pmc.get("compress_layer_f64", [])
+            return name, leaf, comp
+        return None, [], []
+
+    def hash_roofline(self):
+        """The kernels that dominate a proof BY TIME are the leaf / compression layers of the hash that ran, and they are
+        VALU-bound, which the contract's hbm|mfma roofline cannot express.
+          achieved  = permutations / time of one commit of this job's trace tree as the prover runs it (HIP events);
+          frac      = VALU-busy of the launches that make up THIS tree (leaf layer of `rows` lanes, compression layers of rows/2,
+                      rows/4 ... lanes), weighted by their durations, from the committed PMC pass of the hash that ran
+                      (SQ_ACTIVE_INST_VALU / (256 CUs x GRBM_GUI_ACTIVE / 8), <= 1 by construction) — not a constant;
+          sustained_gperm_s = proofs/s x permutations per proof, filled in by bench.py from the timed region;
+          sustained_frac_of_kernel_ceiling = sustained / the rate of the bare permutation kernel measured in this run."""
+        n = self.tree_shapes()[0][0]  # rows of the trace tree (twice as many under hiding: the randomized trace has 2h rows)
         L = _lib.lib()
-        # commit into caller-provided layer storage: the call only enqueues kernels (what the prover does with its arena)
-        layers = torch.empty((L.p3hip_mmcs_layer_words(n),), dtype=torch.int32, device="cuda")
-        ptrs, hs, ws = (C.c_void_p * 1)(x.data_ptr()), (C.c_size_t * 1)(n), (C.c_size_t * 1)(2)
         kind = 1 if self.hash == "keccak" else 0
 
-        def commit():
-            h = C.c_void_p()
-            _lib.check(L.p3hip_mmcs_commit_into_dev(kind, ptrs, hs, ws, 1, C.c_void_p(layers.data_ptr()), C.byref(h), _stream_ptr()))
-            L.p3hip_mmcs_free(h)
-        ms = self._time(commit, 5)
+        def commit_ms(rows, reps):
+            x = torch.randint(0, 0x78000001, (rows, 2), dtype=torch.int32, device="cuda")
+            layers = torch.empty((L.p3hip_mmcs_layer_words(rows),), dtype=torch.int32, device="cuda")
+            ptrs, hs, ws = (C.c_void_p * 1)(x.data_ptr()), (C.c_size_t * 1)(rows), (C.c_size_t * 1)(2)
+
+            def commit():
+                h = C.c_void_p()
+                _lib.check(L.p3hip_mmcs_commit_into_dev(kind, ptrs, hs, ws, 1, C.c_void_p(layers.data_ptr()), C.byref(h), _stream_ptr()))
+                L.p3hip_mmcs_free(h)
+            return self._time(commit, reps)
+        ms = commit_ms(n, 5)
         perms = 2 * n - 1
-        out = {"kernel": "the hash layers as the prover runs them (commit of 2^%d x 2 into pre-allocated layers: leaf_hash_f64_kernel, "
-                         "compress_layer_f64_kernel, tree_levels_coop_kernel%s)" % (self.log_height + self.log_blowup,
-                                                                                   "" if kind == 0 else "; Keccak kernels under --hash keccak"),
-               "achieved": perms / (ms * 1e-3) / 1e9, "unit": "Gperm/s", "permutations": perms, "avg_us": ms * 1e3,
-               "raw_permute_kernel_gperm_s": self.poseidon2_rate() / 1e9,
-               "note": "achieved includes the latency-bound small layers of the tree (below 2^15 digests, ~50 us); the layers of >= 2^20 "
-                       "lanes alone run at 6.8-7.0 Gperm/s (profiles/r02_pmc_poseidon2.json)"}
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        try:
-            with open(os.path.join(root, "profiles", "r02_pmc_poseidon2.json")) as f:
-                pmc = json.load(f)
-            out["frac"] = pmc["summary"]["valu_busy_frac"]
-            out["bound"] = "valu"
-            out["frac_source"] = "profiles/r02_pmc_poseidon2.json (" + pmc["summary"]["definition"] + ")"
-            out["instructions_per_permutation"] = pmc["summary"].get("valu_insts_per_permutation")
-        except Exception:
-            out["frac"] = None
-            out["frac_source"] = "profiles/r02_pmc_poseidon2.json missing: no counter evidence committed yet"
+        big_rows = 1 << 24  # a tree whose layers fill the chip for many workgroup generations: the kernels' own ceiling
+        ms_big = commit_ms(big_rows, 2)
+        hname = "Keccak-f[1600]" if kind else "Poseidon2-BabyBear-16"
+        out = {"bound": "valu", "hash": hname, "unit": "Gperm/s",
+               "kernel": "the hash layers as the prover runs them: one commit of 2^%d x 2 into pre-allocated layers (%s)" % (
+                   self.log_height + self.log_blowup,
+                   "keccak_leaf_kernel, keccak_compress_kernel, keccak_tree_levels[_coop]_kernel" if kind else
+                   "leaf_hash_f64_kernel, compress_layer_f64_kernel, tree_levels_coop_kernel"),
+               "achieved": perms / (ms * 1e-3) / 1e9, "permutations": perms, "avg_us": ms * 1e3,
+               "permutations_per_proof": self.permutations_per_proof()}
+        out["bare_permute_kernel_gperm_s"] = (self.keccak_rate() if kind else self.poseidon2_rate()) / 1e9
+        out["kernel_ceiling_gperm_s"] = (2 * big_rows - 1) / (ms_big * 1e-3) / 1e9
+        src, leaf, comp = self._pmc_rows()
+        if src is None:
+            out.update(frac=None, frac_source="no PMC pass committed for this hash configuration")
+            return out
+        # the launches of this tree: leaf layer of n lanes, compression layers of n/2, n/4, ... lanes (one state per lane)
+        want = [("leaf", n)] + [("compress", n >> k) for k in range(1, 30) if (n >> k) >= 1]
+        used, busy_t, dur_t = [], 0.0, 0.0
+        for what, lanes in want:
+            rows = leaf if what == "leaf" else comp
+            hit = [r for r in rows if r["grid_threads"] == lanes and "valu_busy_frac" in r]
+            if not hit:
+                continue
+            r = hit[-1]
+            busy_t += r["valu_busy_frac"] * r["duration_us"]
+            dur_t += r["duration_us"]
+            used.append({"layer": what, "lanes": lanes, "valu_busy": round(r["valu_busy_frac"], 4), "us": round(r["duration_us"], 1)})
+        big = [r for r in comp if r["grid_threads"] >= (1 << 20) and "valu_insts_per_wave" in r]
+        out["frac"] = busy_t / dur_t if dur_t else None
+        out["frac_source"] = ("profiles/%s: duration-weighted VALU-busy (SQ_ACTIVE_INST_VALU / (256 CUs x GRBM_GUI_ACTIVE / 8 XCDs)) over the "
+                              "per-lane launches of this job's 2^%d-leaf tree; the layers below the cooperative threshold (latency-bound, "
+                              "< 1 %% of the permutations) are not in it" % (src, self.log_height + self.log_blowup))
+        out["frac_layers"] = used
+        out["instructions_per_permutation"] = (sum(r["valu_insts_per_wave"] for r in big) / len(big)) if big else None
         return out
 
     def step_begin(self, instances=None, sink=None):
@@ -320,6 +384,15 @@ class FibAirJob:
         ms = self._time(lambda: _lib.check(L.p3hip_poseidon2_permute_dev(C.c_void_p(st.data_ptr()), n, _stream_ptr())), reps)
         return n / (ms * 1e-3)
 
+    def keccak_rate(self, reps=5):
+        """Keccak-f[1600] permutations/s of the one-state-per-lane kernel: 2^22 random states (25 x u64 each) in HBM.  The full
+        24 rounds with all 25 lanes loaded and stored: the tree kernels' digest-only last round and 4-word stores are cheaper."""
+        n = 1 << 22
+        st = torch.randint(-(1 << 62), 1 << 62, (n, 25), dtype=torch.int64, device="cuda")
+        L = _lib.lib()
+        ms = self._time(lambda: _lib.check(L.p3hip_keccak_f_dev(C.c_void_p(st.data_ptr()), n, _stream_ptr())), reps)
+        return n / (ms * 1e-3)
+
     def stage_breakdown(self):
         trace = generate_trace_rows(0, 1, self.n)
         t_trace = self._time(lambda: generate_trace_rows(0, 1, self.n), 5)
@@ -404,11 +477,23 @@ class WideCommitJob:
         t_lde = self._time(self._lde, 10)
         t_commit = self._time(self._commit, 10)
         perms = H * ((self.width + 7) // 8) + H - 1 if self.hash == "poseidon2" else H * ((((self.width + 1) // 2) + 16) // 17) + H - 1
+        traffic, src = None, None
+        try:
+            import json
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            with open(os.path.join(root, "profiles", "r03_pmc_lde.json")) as f:
+                pmc = json.load(f)
+            if (self.log_height, self.width, self.log_blowup) == (16, 2633, 1) and "cfg5_lde_2^16x2633_blowup2" in pmc:
+                traffic = pmc["cfg5_lde_2^16x2633_blowup2"]["total_bytes"]
+                src = ("profiles/r03_pmc_lde.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, summed over the "
+                       "unit's launches (tools/pmc_probe.py, tools/pmc_summarize.py)")
+        except Exception:
+            pass
         return {"bound": "hbm", "kernel": "coset_lde_batch of the wide matrix (general plans: ntt_fast kernels)",
                 "achieved": lde_bytes / (t_lde * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                 "frac": lde_bytes / (t_lde * 1e-3) / 1e9 / 8000.0,
                 "frac_of_achievable_6300": lde_bytes / (t_lde * 1e-3) / 1e9 / 6300.0,
-                "algorithmic_bytes": lde_bytes, "avg_us": t_lde * 1e3, "traffic": None,
+                "algorithmic_bytes": lde_bytes, "avg_us": t_lde * 1e3, "traffic": traffic, "traffic_source": src,
                 "commit": {"bound": "valu (hash)", "algorithmic_bytes": commit_bytes, "avg_us": t_commit * 1e3,
                            "achieved_gbps": commit_bytes / (t_commit * 1e-3) / 1e9, "permutations": perms,
                            "gperm_s": perms / (t_commit * 1e-3) / 1e9}}

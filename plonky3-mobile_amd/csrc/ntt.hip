@@ -903,6 +903,15 @@ int launch_narrow64(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32
 }
 
 // Narrow-matrix coset LDE in three launches (ntt_narrow.hip.h).  Returns 1 when the shape is not covered.
+// WIDE matrices (more than 16 columns, any width incl. odd ones) on the same two-digit plan: single columns per lane and tiles
+// of 2^8 rows x 32 words, i.e. 128-byte row segments (the slots of a row group are its words in memory order, so a tile may
+// straddle rows).  Instantiated for 8-stage digits: 2^16 rows — BASELINE configs[4], 2^16 x 2633.
+template <int K>
+int launch_narrow_wide(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t blocks, uint32_t gy, bool f64) {
+    if (f64) return launch_narrow64_t<8, 5, 1, K>(cx, stream, a, blocks, gy);
+    return launch_narrow_t<8, 5, 1, K>(cx, stream, a, blocks, gy);
+}
+
 // from_coeffs: src holds the COEFFICIENTS of the columns (natural order, 2^n rows) instead of evaluations over the subgroup:
 // K1 and the inverse half of K2 are skipped (two launches; the hiding prover's blinded quotient chunks arrive that way).
 int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* dst, uint32_t n, uint32_t added, uint32_t W,
@@ -913,9 +922,11 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     static uint32_t w_max = [] { const char* e = getenv("P3HIP_NTT_NARROW_WMAX"); return e ? (uint32_t)atoi(e) : 16u; }();
     // 32-byte row segments per tile: faster than the general plans up to W = 16 (1.3-2.1x), level from W = 32 on
     // W = 6 (the hiding prover's randomized trace, fib_air.rs:65: 2 columns + 4 random codewords): three column pairs per row
-    if (W < 2 || W > w_max || !(is_pow2(W) || W == 6)) return 1;
+    static int wide_on = [] { const char* e = getenv("P3HIP_NTT_NARROW_WIDE"); return e ? atoi(e) : 1; }();
+    const bool wide = W > w_max && wide_on && n == 16 && W >= 64;  // 128-byte tile rows, single columns: any width
+    if (!wide && (W < 2 || W > w_max || !(is_pow2(W) || W == 6))) return 1;
     if (n < n_min || n < 16 || n > 24) return 1;
-    if ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 7u) return 1;  // 8-byte accesses
+    if (!wide && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 7u)) return 1;  // 8-byte accesses
     const uint32_t n1 = (n + 1) / 2, n2 = n - n1;
     const uint64_t N = 1ull << n;
     // lane vector: column pairs, or single columns where that doubles a thin grid's waves per SIMD
@@ -924,6 +935,8 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     // measured (tools/lde_sweep.py): single columns win by 15-25 % up to 2^19 rows (1-2 waves per SIMD otherwise), only
     // for the middle kernel at 2^20 (26.5 -> 23.7 us), and lose from 2^21 on (the grid is full; twice the twiddle work)
     for (int k = 0; k < 3; k++) vw[k] = force_vw == 1 || force_vw == 2 ? force_vw : (n <= 19 || (n == 20 && k == 1) ? 1 : 2);
+    if (wide) vw[0] = vw[1] = vw[2] = 1;
+    auto lq_of = [&](int k, uint32_t b) -> uint32_t { return wide ? 5u : (uint32_t)narrow_lq((int)b, vw[k]); };
     int rc = cx.ws(stream, 1).reserve(N * W * 4);
     if (rc) return rc;
     uint32_t* T = cx.ws(stream, 1).as<uint32_t>();
@@ -952,10 +965,10 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
         const uint32_t slots_per_row = W / vw[k];
         a.spr = slots_per_row;
         a.wsl = is_pow2(slots_per_row) ? log2u(slots_per_row) : 0xffffffffu;
-        const uint32_t lq = narrow_lq(b, vw[k]);
+        const uint32_t lq = lq_of(k, b);
         const uint32_t tiles = (uint32_t)((rows * slots_per_row) >> lq);
-        const uint32_t group = 8u << ((vw[k] == 2 ? 4 : 5) - lq);  // tiles per 128-byte line x 8 XCDs
-        a.xcd_remap = k != 2 && tiles % group == 0 && is_pow2(slots_per_row);
+        const uint32_t group = 8u << (wide ? 0 : (vw[k] == 2 ? 4 : 5) - lq);  // tiles per 128-byte line x 8 XCDs
+        a.xcd_remap = !wide && k != 2 && tiles % group == 0 && is_pow2(slots_per_row);
         return tiles;
     };
     // K1
@@ -967,10 +980,10 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     // and at 2^20 x 2, and LOSES from 2^21 rows on, where twice the LDS per workgroup halves the waves per SIMD.  Default:
     // fp64 where it wins; P3HIP_NTT_NARROW_F64 = 0 keeps the integer kernels, 1..7 is a bit mask (1 = K1, 2 = K2, 4 = K3).
     static int f64_env = [] { const char* e = getenv("P3HIP_NTT_NARROW_F64"); return e ? atoi(e) : -1; }();
-    const int f64_mask = f64_env >= 0 ? f64_env : ((n <= 19 || (n == 20 && W == 2)) ? 7 : 0);
+    const int f64_mask = f64_env >= 0 ? f64_env : ((!wide && (n <= 19 || (n == 20 && W == 2))) ? 7 : 0);  // wide: 2143 us integer, 2287 us fp64
     auto f64 = [&](int k, uint32_t b) {
         if (!((f64_mask >> k) & 1)) return false;
-        return b - 4 + (uint32_t)narrow_lq((int)b, vw[k]) <= (k == 1 ? 9u : 10u);
+        return b - 4 + lq_of(k, b) <= (k == 1 ? 9u : 10u);
     };
     a.stage_twd = cx.tile_twd[1];
     a.neg_pm1 = -2013265920.0; a.pinv = 1.0 / 2013265921.0; a.fbias = -0.5 + 1.0 / 8589934592.0;
@@ -985,7 +998,8 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     }
 #endif
     if (!from_coeffs)
-        if ((rc = f64(0, n1) ? launch_narrow64<1>(cx, stream, a, n1, tiles, vw[0]) : launch_narrow<1>(cx, stream, a, n1, tiles, vw[0]))) return rc;
+        if ((rc = wide ? launch_narrow_wide<1>(cx, stream, a, tiles, 1, f64(0, n1))
+                       : f64(0, n1) ? launch_narrow64<1>(cx, stream, a, n1, tiles, vw[0]) : launch_narrow<1>(cx, stream, a, n1, tiles, vw[0]))) return rc;
 #if NARROW_STAMPS
     if (a.stamps) {
         std::vector<unsigned long long> h((size_t)tiles * 32);
@@ -1026,14 +1040,16 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     if (cos_split < 0) { while (split_log < added && ((uint64_t)tiles << (split_log + 1)) <= 256) split_log++; }
     else split_log = std::min<uint32_t>((uint32_t)cos_split, added);
     a.cos_per_block = (1u << added) >> split_log;
-    if ((rc = f64(1, n2) ? launch_narrow64<2>(cx, stream, a, n2, tiles, vw[1], 1u << split_log)
-                         : launch_narrow<2>(cx, stream, a, n2, tiles, vw[1], 1u << split_log))) return rc;
+    if ((rc = wide ? launch_narrow_wide<2>(cx, stream, a, tiles, 1u << split_log, f64(1, n2))
+                   : f64(1, n2) ? launch_narrow64<2>(cx, stream, a, n2, tiles, vw[1], 1u << split_log)
+                                : launch_narrow<2>(cx, stream, a, n2, tiles, vw[1], 1u << split_log))) return rc;
     // K3
     a.src = mid; a.dst = dst;
     a.stage_tw = cx.tile_tw[0];
     a.stage_twd = cx.tile_twd[0];
     tiles = geometry(2, n1, (1ull << added) << n2);
     a.k3_pairs = k3_out_of_place && vw[2] == 2 && tiles % 16 == 0;
+    if (wide) return launch_narrow_wide<3>(cx, stream, a, tiles, 1, f64(2, n1));
     return f64(2, n1) ? launch_narrow64<3>(cx, stream, a, n1, tiles, vw[2]) : launch_narrow<3>(cx, stream, a, n1, tiles, vw[2]);
 }
 

@@ -37,4 +37,13 @@ t20 = p3.generate_trace_rows(0, 1, 1 << 20)
 for _ in range(3):
     y = dft.coset_lde_batch(t20, 1, p3.GENERATOR_MONTY, bit_reversed_out=True)
 torch.cuda.synchronize()
+del y, t20
+# subject: the wide trace of BASELINE configs[4], 2^16 x 2633, blowup 2 (general plans).  Marker launch right before it: the only
+# fib_trace of 2^10 rows in this run; the summariser sums every transform launch after the LAST marker.
+from plonky3_mobile_amd.fib_air import benchmark_input  # noqa: E402
+xw = p3.dev_u32(benchmark_input(1 << 16, 2633))
+for _ in range(2):
+    p3.generate_trace_rows(0, 1, 1 << 10)
+    y = dft.coset_lde_batch(xw, 1, p3.GENERATOR_MONTY, bit_reversed_out=True)
+    torch.cuda.synchronize()
 print("done")

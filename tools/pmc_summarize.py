@@ -55,5 +55,18 @@ for key, names, which, alg in (("cfg3_lde_2^24x2_blowup4", [n + "<12" for n in k
                                ("cfg2_lde_2^20x2_blowup2", [n + "<10" for n in k3], -1, 4 * (1 << 20) * 2 * 3)):
     u = unit(names, which)
     out[key] = {"launches": u, "total_bytes": sum(l["fetch_bytes"] + l["write_bytes"] for l in u), "algorithmic_bytes": alg}
+# BASELINE configs[4]: every transform launch after the last 2^10-row fib_trace marker (tools/pmc_probe.py)
+grids = {}
+for d in (sys.argv[1],):
+    import csv as _csv
+    import glob as _glob
+    for r in _csv.DictReader(open(_glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0])):
+        grids[int(r["Dispatch_Id"])] = int(r["Grid_Size"])
+order = [i for i, _, _ in fetch]
+marks = [k for k, (i, name, _) in enumerate(fetch) if "fib_trace_kernel" in name and grids.get(i, 0) <= 1024]
+if marks:
+    tail = [l for l in launches[marks[-1] + 1:] if "ntt_" in l["kernel"] or "narrow" in l["kernel"] or "bit_reverse" in l["kernel"]]
+    out["cfg5_lde_2^16x2633_blowup2"] = {"launches": tail, "total_bytes": sum(l["fetch_bytes"] + l["write_bytes"] for l in tail),
+                                         "algorithmic_bytes": 4 * (1 << 16) * 2633 * 3}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps({k: (v["total_bytes"], v["algorithmic_bytes"]) for k, v in out.items() if k.startswith("cfg")}))

@@ -181,6 +181,39 @@ __device__ __forceinline__ void to_natural(TL& tiles, DV<VW> (&v)[16], uint32_t 
         for (int cc = 0; cc < VW; cc++) v[j].c[cc] = rp[cc * PL + lds_joff<LQ>(j << (B - 4))];
 }
 
+// The LAST hand-over of K1 (to natural frequency order) and K3 (to row order) on WORDS: the values are reduced for the store
+// anyway, and 4-byte words halve the LDS traffic of that exchange (the tile written is the one next() hands out: the words
+// occupy the front of it, so the tiles' barrier protocol is unchanged).
+template <int B, int LQ, int VW, bool NATURAL, class TL>
+__device__ __forceinline__ void exchange_words(TL& tiles, typename Vec<VW>::T (&w)[16], uint32_t t, uint32_t q) {
+    using V = typename Vec<VW>::T;
+    V* tile = reinterpret_cast<V*>(tiles.next());
+    if constexpr (NATURAL) {
+        const uint32_t rt = rev_bits(t, B - 4);
+        V* wp = tile + (((rt + (rt >> 4)) << LQ) + q);
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) wp[lds_joff<LQ>(crev(j, 4) << (B - 4))] = w[j];
+    } else {
+        V* wp = tile + lds_base<LQ, 0>(t, q);
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) wp[lds_joff<LQ>(j)] = w[j];
+    }
+    __syncthreads();
+    const V* rp = tile + lds_base<LQ, B - 4>(t, q);
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) w[j] = rp[lds_joff<LQ>(j << (B - 4))];
+}
+template <int VW, bool CENTERED>
+__device__ __forceinline__ typename Vec<VW>::T to_words(const DV<VW>& v, const Uni& u) {
+    if constexpr (VW == 2) {
+        if constexpr (CENTERED) return make_uint2(word_centered(v.c[0]), word_centered(v.c[1]));
+        else return make_uint2(word_any(v.c[0], u), word_any(v.c[1], u));
+    } else {
+        if constexpr (CENTERED) return word_centered(v.c[0]);
+        else return word_any(v.c[0], u);
+    }
+}
+
 // pw[r] = c * phi^r for r < 16, by doubling
 __device__ __forceinline__ void power_ladder16(double c, double phi, double (&pw)[16], const Magic& k, const Uni& un) {
     pw[0] = c;
@@ -271,20 +304,24 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow64_inv1_kernel(Narrow
     }
     P3_PIN16(v);
     P3_STAMP(a, 4);
-    to_natural<B, LQ>(tile, v, t, q);
-    P3_PIN16(v);
+    using WV = typename Vec<VW>::T;
+    WV w[16];
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) w[j] = to_words<VW, true>(v[j], un);
+    exchange_words<B, LQ, VW, true>(tile, w, t, q);
+    P3_PIN16(w);
     P3_STAMP(a, 5);
     if (a.blocked) {
         const uint32_t blk_off = ((((lo >> 2) << (B - 2)) + (t >> 2)) * 16u + (lo & 3u) * 4u + (t & 3u)) * 8u + cp * 4u;
 #pragma unroll
-        for (uint32_t j = 0; j < 16; j++) st_words<VW, true>(a.dst + ((uint64_t)j << (B - 6)) * 32u, blk_off, v[j], un);
+        for (uint32_t j = 0; j < 16; j++) stv<WV>(a.dst + ((uint64_t)j << (B - 6)) * 32u, blk_off, w[j]);
         P3_STAMP(a, 6);
         P3_STAMP_RT(a, 31);
         return;
     }
     const uint32_t st_off = (((lo << B) + t) * a.W + VW * cp) * 4u;
 #pragma unroll
-    for (uint32_t j = 0; j < 16; j++) st_words<VW, true>(a.dst + ((uint64_t)j << (B - 4)) * a.W, st_off, v[j], un);
+    for (uint32_t j = 0; j < 16; j++) stv<WV>(a.dst + ((uint64_t)j << (B - 4)) * a.W, st_off, w[j]);
 }
 
 // K2: second inverse digit; per coset: scale by (shift g^j)^k / N, first forward digit, twiddle, strided store.
@@ -392,9 +429,13 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow64_fwd2_kernel(Narrow
     load_round1_twiddles<B>(a.stage_twd, t, w1);
     for (uint32_t i = threadIdx.x; i + 1 < (1u << (B - 4)); i += NTH) twl[i] = a.stage_twd[i];
     dif_rounds<B, LQ>(v, tile, w1, twl, t, q, mk, un);
-    exchange<LQ, 0, B - 4, PL>(tile, v, t, q);  // position order is the wanted order: 16 consecutive lanes hold 16 consecutive rows
+    using WV = typename Vec<VW>::T;
+    WV w[16];
 #pragma unroll
-    for (uint32_t j = 0; j < 16; j++) st_words<VW, false>(p + ((uint64_t)j << (B - 4)) * a.W, off, v[j], un);
+    for (uint32_t j = 0; j < 16; j++) w[j] = to_words<VW, false>(v[j], un);
+    exchange_words<B, LQ, VW, false>(tile, w, t, q);  // position order is the wanted order: 16 consecutive lanes hold 16 consecutive rows
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) stv<WV>(p + ((uint64_t)j << (B - 4)) * a.W, off, w[j]);
 }
 
 }  // namespace p3

@@ -249,6 +249,16 @@ def test_coset_lde_from_coefficients(oracle, p3, log_h, w, ab):
     assert np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("w,ab", [(64, 1), (65, 2), (100, 1), (333, 1), (257, 3)])
+def test_wide_matrices_on_the_two_digit_plan(dft, oracle, p3, w, ab):
+    """2^16 rows x >= 64 columns (any width, odd ones too): the three-launch plan with 128-byte tile rows, whose tiles straddle
+    matrix rows — the shape class of BASELINE configs[4] (2^16 x 2633, tests/test_gpu_cfg5.py holds that size itself)."""
+    rng = np.random.default_rng(16000 + 10 * w + ab)
+    x = _rand(rng, 1 << 16, w)
+    shift = p3.GENERATOR_MONTY if w % 2 == 0 else int(rng.integers(1, P))
+    assert np.array_equal(dft.coset_lde_batch(x, ab, shift, bit_reversed_out=True), oracle.coset_lde_batch(x, ab, shift, True))
+
+
 def test_raw_u32_plan_entry_like_the_reference_benchmark(p3, oracle):
     """prepare_compute_plan(width, height, 0, log_n) + setup_pipeline_plan(&plan, &[u32]) as the reference's benchmark
     drives them (fib_air.rs:128-134): natural-order Montgomery words in and out."""

@@ -35,7 +35,7 @@ for hash_name, kind in (("poseidon2", o.HASH_POSEIDON2), ("keccak", o.HASH_KECCA
 # the narrow three-launch coset LDE (2^16 rows and up) in whichever arithmetic the environment selects: integer or fp64
 # butterflies (P3HIP_NTT_NARROW_F64), column pairs or single columns, one or two LDS tiles
 dft = p3.GpuDft.with_backend(p3.BackendKind.Hip)
-shapes = [(16, 2, 1), (17, 4, 2), (18, 8, 1), (19, 2, 3), (20, 2, 1), (21, 2, 1), (22, 4, 1)]
+shapes = [(16, 2, 1), (17, 4, 2), (18, 8, 1), (19, 2, 3), (20, 2, 1), (21, 2, 1), (22, 4, 1), (16, 6, 1), (16, 77, 1)]
 if os.environ.get("P3HIP_VARIANT_BIG_LDE") == "1":
     shapes.append((23, 2, 1))  # 12-stage digits
 for log_h, w, ab in shapes:

@@ -936,7 +936,10 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     // for the middle kernel at 2^20 (26.5 -> 23.7 us), and lose from 2^21 on (the grid is full; twice the twiddle work)
     for (int k = 0; k < 3; k++) vw[k] = force_vw == 1 || force_vw == 2 ? force_vw : (n <= 19 || (n == 20 && k == 1) ? 1 : 2);
     if (wide) vw[0] = vw[1] = vw[2] = 1;
-    auto lq_of = [&](int k, uint32_t b) -> uint32_t { return wide ? 5u : (uint32_t)narrow_lq((int)b, vw[k]); };
+    // experiment (P3HIP_NTT_NARROW_K3_LQ1=1): K3 with 2-row tiles at 10-stage digits — twice the workgroups, half the waves each
+    static int k3_lq1_env = [] { const char* e = getenv("P3HIP_NTT_NARROW_K3_LQ1"); return e ? atoi(e) : 0; }();
+    const bool k3_lq1 = k3_lq1_env && !wide && n1 == 10 && vw[2] == 2 && W == 2;
+    auto lq_of = [&](int k, uint32_t b) -> uint32_t { return wide ? 5u : (k == 2 && k3_lq1) ? 1u : (uint32_t)narrow_lq((int)b, vw[k]); };
     int rc = cx.ws(stream, 1).reserve(N * W * 4);
     if (rc) return rc;
     uint32_t* T = cx.ws(stream, 1).as<uint32_t>();
@@ -949,7 +952,7 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     static int use_blocked12 = [] { const char* e = getenv("P3HIP_NTT_NARROW_BLOCKED12"); return e ? atoi(e) : 1; }();
     const bool twelve = n1 >= 12 || n2 >= 12;
     a.blocked = use_blocked && !NARROW_MID_SEQ && W == 2 && !from_coeffs && (!twelve || use_blocked12);
-    const bool k3_out_of_place = a.blocked && n1 >= 12;
+    const bool k3_out_of_place = a.blocked && (n1 >= 12 || k3_lq1);
     uint32_t* mid = dst;  // K2's output = K3's input
     if (k3_out_of_place) {
         if ((rc = cx.ws(stream, 3).reserve((N << added) * W * 4))) return rc;
@@ -1050,6 +1053,7 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     tiles = geometry(2, n1, (1ull << added) << n2);
     a.k3_pairs = k3_out_of_place && vw[2] == 2 && tiles % 16 == 0;
     if (wide) return launch_narrow_wide<3>(cx, stream, a, tiles, 1, f64(2, n1));
+    if (k3_lq1) return f64(2, n1) ? launch_narrow64_t<10, 1, 2, 3>(cx, stream, a, tiles, 1) : launch_narrow_t<10, 1, 2, 3>(cx, stream, a, tiles, 1);
     return f64(2, n1) ? launch_narrow64<3>(cx, stream, a, n1, tiles, vw[2]) : launch_narrow<3>(cx, stream, a, n1, tiles, vw[2]);
 }
 

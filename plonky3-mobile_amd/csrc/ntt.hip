@@ -857,14 +857,14 @@ int launch_narrow(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t
 
 // fp64 forms (ntt_narrow_f64.hip.h).  NT = 2 LDS tiles (one barrier per hand-over) where they fit and the grid gives a CU
 // one workgroup anyway; otherwise one tile, so that two workgroups can share a CU.
-template <int B, int LQ, int VW, int K, int NT>
+template <int B, int LQ, int VW, int K, int NT, bool XW>
 int launch_narrow64_nt(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t blocks, uint32_t grid_y) {
-    constexpr size_t lds = narrow64::lds_bytes<B, LQ, VW, NT>(K == 2 ? 2 : 1);
+    constexpr size_t lds = narrow64::lds_bytes<B, LQ, VW, NT, XW>(K == 2 ? 2 : 1);
     static_assert(lds <= 160 * 1024, "fp64 narrow tile does not fit the LDS");
     void (*kern)(NarrowArgs);
-    if constexpr (K == 1) kern = narrow64_inv1_kernel<B, LQ, VW, NT>;
-    else if constexpr (K == 2) kern = narrow64_mid_kernel<B, LQ, VW, NT, (VW == 2)>;
-    else kern = narrow64_fwd2_kernel<B, LQ, VW, NT>;
+    if constexpr (K == 1) kern = narrow64_inv1_kernel<B, LQ, VW, NT, XW>;
+    else if constexpr (K == 2) kern = narrow64_mid_kernel<B, LQ, VW, NT, (VW == 2), XW>;
+    else kern = narrow64_fwd2_kernel<B, LQ, VW, NT, XW>;
     if constexpr (lds > 64 * 1024) {
         int rc = cx.ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds);
         if (rc) return rc;
@@ -873,15 +873,21 @@ int launch_narrow64_nt(Context& cx, hipStream_t stream, const NarrowArgs& a, uin
     P3_HIP(hipGetLastError());
     return OK;
 }
-template <int B, int LQ, int VW, int K>
-int launch_narrow64_t(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t blocks, uint32_t grid_y) {
-    constexpr bool fits2 = narrow64::lds_bytes<B, LQ, VW, 2>(K == 2 ? 2 : 1) <= 160 * 1024;
+// XW: hand-overs on words (tiles of the integer kernels' size) instead of doubles
+template <int B, int LQ, int VW, int K, bool XW>
+int launch_narrow64_x(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t blocks, uint32_t grid_y) {
+    constexpr bool fits2 = narrow64::lds_bytes<B, LQ, VW, 2, XW>(K == 2 ? 2 : 1) <= 160 * 1024;
     static int nt_env = [] { const char* e = getenv("P3HIP_NTT_NARROW_F64_TILES"); return e ? atoi(e) : 0; }();
     if constexpr (fits2) {
-        const bool two = nt_env ? nt_env == 2 : (size_t)blocks * grid_y <= 256 || narrow64::lds_bytes<B, LQ, VW, 2>(K == 2 ? 2 : 1) <= 80 * 1024;
-        if (two) return launch_narrow64_nt<B, LQ, VW, K, 2>(cx, stream, a, blocks, grid_y);
+        const bool two = nt_env ? nt_env == 2 : (size_t)blocks * grid_y <= 256 || narrow64::lds_bytes<B, LQ, VW, 2, XW>(K == 2 ? 2 : 1) <= 80 * 1024;
+        if (two) return launch_narrow64_nt<B, LQ, VW, K, 2, XW>(cx, stream, a, blocks, grid_y);
     }
-    return launch_narrow64_nt<B, LQ, VW, K, 1>(cx, stream, a, blocks, grid_y);
+    return launch_narrow64_nt<B, LQ, VW, K, 1, XW>(cx, stream, a, blocks, grid_y);
+}
+template <int B, int LQ, int VW, int K>
+int launch_narrow64_t(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t blocks, uint32_t grid_y) {
+    return a.f64_words ? launch_narrow64_x<B, LQ, VW, K, true>(cx, stream, a, blocks, grid_y)
+                       : launch_narrow64_x<B, LQ, VW, K, false>(cx, stream, a, blocks, grid_y);
 }
 // 1024-thread workgroups (128 VGPRs per lane) are left to the integer kernels: K2 at single columns from 11 stages on
 constexpr bool narrow64_has(int b, int vw, int k) { return b - 4 + narrow_lq(b, vw) <= (k == 2 ? 9 : 10); }
@@ -988,6 +994,10 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
         if (!((f64_mask >> k) & 1)) return false;
         return b - 4 + lq_of(k, b) <= (k == 1 ? 9u : 10u);
     };
+    // fp64 kernels: hand-overs as doubles, or as words (P3HIP_NTT_NARROW_F64_XW=1; tiles of the integer kernels' size, five more
+    // instructions per element and hand-over)
+    static int xw_env = [] { const char* e = getenv("P3HIP_NTT_NARROW_F64_XW"); return e ? atoi(e) : -1; }();
+    a.f64_words = xw_env >= 0 ? (uint32_t)xw_env : 0u;
     a.stage_twd = cx.tile_twd[1];
     a.neg_pm1 = -2013265920.0; a.pinv = 1.0 / 2013265921.0; a.fbias = -0.5 + 1.0 / 8589934592.0;
     uint32_t tiles = geometry(0, n1, 1ull << n2);

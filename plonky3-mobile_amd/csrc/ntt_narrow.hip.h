@@ -114,6 +114,7 @@ struct NarrowArgs {
     const double2* stage_twd;
     const double2* stage_twd_fwd;
     double neg_pm1, pinv, fbias;  // -(P - 1), 1 / P, -1/2 + 2^-33: uniform operands of the fp64 product / floor reduction
+    uint32_t f64_words;           // fp64 kernels: host-side choice of the hand-over form (doubles / words), not read by kernels
     uint32_t k3_pairs;            // K3 with 2-row tiles over blocked input: partner tiles (the two halves of every 128-byte block)
                                   // go to one XCD; K3 then reads a.src (out of place: in place the partner's half would be overwritten)
     uint32_t blocked;             // W = 2: the two intermediates are stored in 128-byte blocks of

@@ -149,16 +149,47 @@ __device__ __forceinline__ void exchange(TL& tiles, DV<VW> (&v)[16], uint32_t t,
 #pragma unroll
         for (int cc = 0; cc < VW; cc++) v[j].c[cc] = rp[cc * PL + lds_joff<LQ>(j << AT)];
 }
-template <int B, int LQ, int VW, class TL>
+// word of any integer |x| < 2^43 (defined below)
+__device__ __forceinline__ uint32_t word_any(double x, const Uni& u);
+template <int VW>
+__device__ __forceinline__ DV<VW> from_words(const typename Vec<VW>::T& x) {
+    DV<VW> r;
+    if constexpr (VW == 2) { r.c[0] = (double)x.x; r.c[1] = (double)x.y; }
+    else r.c[0] = (double)x;
+    return r;
+}
+template <int VW>
+__device__ __forceinline__ typename Vec<VW>::T words_of(const DV<VW>& v, const Uni& u) {
+    if constexpr (VW == 2) return make_uint2(word_any(v.c[0], u), word_any(v.c[1], u));
+    else return word_any(v.c[0], u);
+}
+// The same hand-over on WORDS (XW kernels): every value is reduced to its word on the way in (4 instructions) and converted back on
+// the way out (1): five instructions per element instead of twice the LDS bytes — the tiles, and with them the workgroups per CU, are
+// those of the integer kernels.
+template <int LQ, int AF, int AT, int VW, class TL>
+__device__ __forceinline__ void exchange_xw(TL& tiles, DV<VW> (&v)[16], uint32_t t, uint32_t q, const Uni& un) {
+    using WV = typename Vec<VW>::T;
+    WV* tile = reinterpret_cast<WV*>(tiles.next());
+    WV* wp = tile + lds_base<LQ, AF>(t, q);
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) wp[lds_joff<LQ>(j << AF)] = words_of<VW>(v[j], un);
+    __syncthreads();
+    const WV* rp = tile + lds_base<LQ, AT>(t, q);
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) v[j] = from_words<VW>(rp[lds_joff<LQ>(j << AT)]);
+}
+template <int B, int LQ, bool XW, int VW, class TL>
 __device__ __forceinline__ void dif_rounds(DV<VW> (&v)[16], TL& tile, const double (&w1)[15], const double2* twl, uint32_t t, uint32_t q,
                                            const Magic& k, const Uni& un) {
     constexpr int A1 = B - 4, A2 = B > 8 ? B - 8 : 0;
     constexpr uint32_t PL = lds_rows(B) << LQ;
     stage_block_round1(v, w1, k, un);
-    exchange<LQ, A1, A2, PL>(tile, v, t, q);
+    if constexpr (XW) exchange_xw<LQ, A1, A2>(tile, v, t, q, un);
+    else exchange<LQ, A1, A2, PL>(tile, v, t, q);
     stage_block<A2, A1, A2>(v, twl, t, k, un.npm1);
     if constexpr (B > 8) {
-        exchange<LQ, A2, 0, PL>(tile, v, t, q);
+        if constexpr (XW) exchange_xw<LQ, A2, 0>(tile, v, t, q, un);
+        else exchange<LQ, A2, 0, PL>(tile, v, t, q);
         stage_block<0, A2, 0>(v, twl, t, k, un.npm1);
     }
 }
@@ -179,6 +210,20 @@ __device__ __forceinline__ void to_natural(TL& tiles, DV<VW> (&v)[16], uint32_t 
     for (uint32_t j = 0; j < 16; j++)
 #pragma unroll
         for (int cc = 0; cc < VW; cc++) v[j].c[cc] = rp[cc * PL + lds_joff<LQ>(j << (B - 4))];
+}
+
+template <int B, int LQ, int VW, class TL>
+__device__ __forceinline__ void to_natural_xw(TL& tiles, DV<VW> (&v)[16], uint32_t t, uint32_t q, const Uni& un) {
+    using WV = typename Vec<VW>::T;
+    WV* tile = reinterpret_cast<WV*>(tiles.next());
+    const uint32_t rt = rev_bits(t, B - 4);
+    WV* wp = tile + (((rt + (rt >> 4)) << LQ) + q);
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) wp[lds_joff<LQ>(crev(j, 4) << (B - 4))] = words_of<VW>(v[j], un);
+    __syncthreads();
+    const WV* rp = tile + lds_base<LQ, B - 4>(t, q);
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) v[j] = from_words<VW>(rp[lds_joff<LQ>(j << (B - 4))]);
 }
 
 // The LAST hand-over of K1 (to natural frequency order) and K3 (to row order) on WORDS: the values are reduced for the store
@@ -237,22 +282,23 @@ __device__ __forceinline__ void scale_by(DV<VW> (&v)[16], const double (&pw)[16]
     }
 }
 
-template <int B, int LQ, int VW, int NT>
+template <int B, int LQ, int VW, int NT, bool XW>
 constexpr size_t lds_bytes(int tables) {
-    return ((size_t)8 * VW * NT * lds_rows(B) << LQ) + (size_t)tables * ((size_t)16 << (B - 4));
+    return ((size_t)(XW ? 4 : 8) * VW * NT * lds_rows(B) << LQ) + (size_t)tables * ((size_t)16 << (B - 4));
 }
 
 }  // namespace narrow64
 
 // K1: first inverse digit (the high n1 bits of the row index), inter-digit twiddle, transposed store.
-template <int B, int LQ, int VW, int NT>
+template <int B, int LQ, int VW, int NT, bool XW>
 __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow64_inv1_kernel(NarrowArgs a) {
     using namespace narrow64;
     constexpr uint32_t NQ = 1u << LQ, NTH = 1u << (B - 4 + LQ), PL = lds_rows(B) << LQ;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     double* t0 = reinterpret_cast<double*>(smem);
-    Tiles<double, (NT > 1)> tile{t0, t0 + (NT - 1) * VW * PL};
-    double2* twl = reinterpret_cast<double2*>(t0 + NT * VW * PL);
+    constexpr uint32_t TD = XW ? VW * PL / 2 : VW * PL;  // doubles per tile (a tile of words is half as large)
+    Tiles<double, (NT > 1)> tile{t0, t0 + (NT - 1) * TD};
+    double2* twl = reinterpret_cast<double2*>(t0 + NT * TD);
     const Magic mk = pin_magic();
     const Uni un{a.neg_pm1, a.pinv, a.fbias};
     const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> LQ;
@@ -279,21 +325,21 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow64_inv1_kernel(Narrow
         stage_block_round1(v, w1, mk, un);
         P3_PIN16(v);
         P3_STAMP(a, 8);
-        exchange<LQ, A1, A2, PL>(tile, v, t, q);
+        if constexpr (XW) exchange_xw<LQ, A1, A2>(tile, v, t, q, un); else exchange<LQ, A1, A2, PL>(tile, v, t, q);
         P3_PIN16(v);
         P3_STAMP(a, 9);
         stage_block<A2, A1, A2>(v, twl, t, mk, un.npm1);
         P3_PIN16(v);
         P3_STAMP(a, 10);
         if constexpr (B > 8) {
-            exchange<LQ, A2, 0, PL>(tile, v, t, q);
+            if constexpr (XW) exchange_xw<LQ, A2, 0>(tile, v, t, q, un); else exchange<LQ, A2, 0, PL>(tile, v, t, q);
             P3_PIN16(v);
             P3_STAMP(a, 11);
             stage_block<0, A2, 0>(v, twl, t, mk, un.npm1);
         }
     }
 #else
-    dif_rounds<B, LQ>(v, tile, w1, twl, t, q, mk, un);
+    dif_rounds<B, LQ, XW>(v, tile, w1, twl, t, q, mk, un);
 #endif
     P3_PIN16(v);
     P3_STAMP(a, 3);
@@ -325,14 +371,15 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow64_inv1_kernel(Narrow
 }
 
 // K2: second inverse digit; per coset: scale by (shift g^j)^k / N, first forward digit, twiddle, strided store.
-template <int B, int LQ, int VW, int NT, bool LEAN>
+template <int B, int LQ, int VW, int NT, bool LEAN, bool XW>
 __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow64_mid_kernel(NarrowArgs a) {
     using namespace narrow64;
     constexpr uint32_t NQ = 1u << LQ, NTH = 1u << (B - 4 + LQ), PL = lds_rows(B) << LQ;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     double* t0 = reinterpret_cast<double*>(smem);
-    Tiles<double, (NT > 1)> tile{t0, t0 + (NT - 1) * VW * PL};
-    double2* twl_i = reinterpret_cast<double2*>(t0 + NT * VW * PL);
+    constexpr uint32_t TD = XW ? VW * PL / 2 : VW * PL;
+    Tiles<double, (NT > 1)> tile{t0, t0 + (NT - 1) * TD};
+    double2* twl_i = reinterpret_cast<double2*>(t0 + NT * TD);
     double2* twl_f = twl_i + (1u << (B - 4));
     const Magic mk = pin_magic();
     const Uni un{a.neg_pm1, a.pinv, a.fbias};
@@ -354,14 +401,17 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow64_mid_kernel(NarrowA
         load_round1_twiddles<B>(a.stage_twd, t, w1);
         for (uint32_t i = threadIdx.x; i + 1 < (1u << (B - 4)); i += NTH) twl_i[i] = a.stage_twd[i];
         for (uint32_t i = threadIdx.x; i + 1 < (1u << (B - 4)); i += NTH) twl_f[i] = a.stage_twd_fwd[i];
-        if (!a.from_coeffs) dif_rounds<B, LQ>(c, tile, w1, twl_i, t, q, mk, un);
+        if (!a.from_coeffs) dif_rounds<B, LQ, XW>(c, tile, w1, twl_i, t, q, mk, un);
     }
     const double c0 = canon(two_level(a.twf_lo, a.twf_hi, a.twf_T, (uint64_t)k1 * rev_bits(t, B - 4)));
     const double phi0 = canon(two_level(a.twf_lo, a.twf_hi, a.twf_T, (uint64_t)k1 << (B - 4)));
     const uint64_t kbase = (uint64_t)k1 + ((uint64_t)t << a.n1);
     const uint32_t cos0 = blockIdx.y * a.cos_per_block, ncos = cos0 + a.cos_per_block;
     uint32_t sc_next = two_level(a.sc_lo[cos0], a.sc_hi[cos0], a.sc_T, kbase);
-    if (!a.from_coeffs) to_natural<B, LQ>(tile, c, t, q);  // c[j] = coefficient k = k1 + N1 * k2, k2 = (j << (B-4)) | t
+    if (!a.from_coeffs) {  // c[j] = coefficient k = k1 + N1 * k2, k2 = (j << (B-4)) | t
+        if constexpr (XW) to_natural_xw<B, LQ>(tile, c, t, q, un);
+        else to_natural<B, LQ>(tile, c, t, q);
+    }
     double pw2[16];
     if constexpr (!LEAN) power_ladder16(c0, phi0, pw2, mk, un);
     for (uint32_t jc = cos0; jc < ncos; jc++) {
@@ -380,7 +430,7 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow64_mid_kernel(NarrowA
                 for (int cc = 0; cc < VW; cc++) v[j].c[cc] = mulm(w, wP, c[j].c[cc], mk, un.npm1);
             }
         }
-        dif_rounds<B, LQ>(v, tile, w1, twl_f, t, q, mk, un);
+        dif_rounds<B, LQ, XW>(v, tile, w1, twl_f, t, q, mk, un);
         if constexpr (LEAN) power_ladder16(c0, phi0, pw2, mk, un);
         scale_by<true>(v, pw2, mk, un);
         uint32_t* o = a.dst + ((uint64_t)rev_bits(jc, a.added) << a.n) * a.W;  // position (t << 4) | j of the coset's block
@@ -398,14 +448,15 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow64_mid_kernel(NarrowA
 }
 
 // K3: last forward digit on contiguous blocks of 2^B rows, in place.
-template <int B, int LQ, int VW, int NT>
+template <int B, int LQ, int VW, int NT, bool XW>
 __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow64_fwd2_kernel(NarrowArgs a) {
     using namespace narrow64;
     constexpr uint32_t NQ = 1u << LQ, NTH = 1u << (B - 4 + LQ), PL = lds_rows(B) << LQ;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     double* t0 = reinterpret_cast<double*>(smem);
-    Tiles<double, (NT > 1)> tile{t0, t0 + (NT - 1) * VW * PL};
-    double2* twl = reinterpret_cast<double2*>(t0 + NT * VW * PL);
+    constexpr uint32_t TD = XW ? VW * PL / 2 : VW * PL;  // doubles per tile (a tile of words is half as large)
+    Tiles<double, (NT > 1)> tile{t0, t0 + (NT - 1) * TD};
+    double2* twl = reinterpret_cast<double2*>(t0 + NT * TD);
     const Magic mk = pin_magic();
     const Uni un{a.neg_pm1, a.pinv, a.fbias};
     const uint32_t q = threadIdx.x & (NQ - 1), t = threadIdx.x >> LQ;
@@ -428,7 +479,7 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow64_fwd2_kernel(Narrow
     double w1[15];
     load_round1_twiddles<B>(a.stage_twd, t, w1);
     for (uint32_t i = threadIdx.x; i + 1 < (1u << (B - 4)); i += NTH) twl[i] = a.stage_twd[i];
-    dif_rounds<B, LQ>(v, tile, w1, twl, t, q, mk, un);
+    dif_rounds<B, LQ, XW>(v, tile, w1, twl, t, q, mk, un);
     using WV = typename Vec<VW>::T;
     WV w[16];
 #pragma unroll

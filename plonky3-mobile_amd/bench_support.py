@@ -486,10 +486,13 @@ class WideCommitJob:
             if (self.log_height, self.width, self.log_blowup) == (16, 2633, 1) and "cfg5_lde_2^16x2633_blowup2" in pmc:
                 traffic = pmc["cfg5_lde_2^16x2633_blowup2"]["total_bytes"]
                 src = ("profiles/r03_pmc_lde.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, summed over the "
-                       "unit's launches (tools/pmc_probe.py, tools/pmc_summarize.py)")
+                       "unit's launches (tools/pmc_probe.py, tools/pmc_summarize.py).  An UPPER bound: the x2 is calibrated for aligned "
+                       "16-byte-per-lane reads; this plan reads 4 bytes per lane and the rows of a 2633-word matrix are not multiples of 128 "
+                       "bytes: K3's 2.73 GB stands for 1.38 GB of reads either counted or fetched twice (a tile order that gives neighbours in a "
+                       "row to one XCD changed neither the counter nor the time).  The structure moves 6.2 GB = 9 matrix sweeps")
         except Exception:
             pass
-        return {"bound": "hbm", "kernel": "coset_lde_batch of the wide matrix (general plans: ntt_fast kernels)",
+        return {"bound": "hbm", "kernel": "coset_lde_batch of the wide matrix (two-digit plan with 128-byte tile rows: narrow_inv1 / narrow_mid / narrow_fwd2 <8, 5, 1>)",
                 "achieved": lde_bytes / (t_lde * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                 "frac": lde_bytes / (t_lde * 1e-3) / 1e9 / 8000.0,
                 "frac_of_achievable_6300": lde_bytes / (t_lde * 1e-3) / 1e9 / 6300.0,

@@ -978,6 +978,7 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
         const uint32_t tiles = (uint32_t)((rows * slots_per_row) >> lq);
         const uint32_t group = 8u << (wide ? 0 : (vw[k] == 2 ? 4 : 5) - lq);  // tiles per 128-byte line x 8 XCDs
         a.xcd_remap = !wide && k != 2 && tiles % group == 0 && is_pow2(slots_per_row);
+        if (wide && tiles % 128 == 0) a.xcd_remap = 4;  // 16 consecutive tiles (2 KB of a row) per XCD
         return tiles;
     };
     // K1
@@ -1061,7 +1062,8 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     a.stage_tw = cx.tile_tw[0];
     a.stage_twd = cx.tile_twd[0];
     tiles = geometry(2, n1, (1ull << added) << n2);
-    a.k3_pairs = k3_out_of_place && vw[2] == 2 && tiles % 16 == 0;
+    a.k3_pairs = k3_out_of_place && vw[2] == 2 && tiles % 16 == 0 ? 1u : 0u;
+    if (wide && tiles % 128 == 0) a.k3_pairs = 4;
     if (wide) return launch_narrow_wide<3>(cx, stream, a, tiles, 1, f64(2, n1));
     if (k3_lq1) return f64(2, n1) ? launch_narrow64_t<10, 1, 2, 3>(cx, stream, a, tiles, 1) : launch_narrow_t<10, 1, 2, 3>(cx, stream, a, tiles, 1);
     return f64(2, n1) ? launch_narrow64<3>(cx, stream, a, n1, tiles, vw[2]) : launch_narrow<3>(cx, stream, a, n1, tiles, vw[2]);

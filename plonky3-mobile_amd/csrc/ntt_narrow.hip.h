@@ -115,8 +115,9 @@ struct NarrowArgs {
     const double2* stage_twd_fwd;
     double neg_pm1, pinv, fbias;  // -(P - 1), 1 / P, -1/2 + 2^-33: uniform operands of the fp64 product / floor reduction
     uint32_t f64_words;           // fp64 kernels: host-side choice of the hand-over form (doubles / words), not read by kernels
-    uint32_t k3_pairs;            // K3 with 2-row tiles over blocked input: partner tiles (the two halves of every 128-byte block)
-                                  // go to one XCD; K3 then reads a.src (out of place: in place the partner's half would be overwritten)
+    uint32_t k3_pairs;            // K3: log2 of the consecutive tiles dealt to one XCD.  1 with 2-row tiles over blocked input (partner tiles =
+                                  // the two halves of every 128-byte block; K3 then reads a.src out of place: in place the partner's half
+                                  // would be overwritten); 4 for wide matrices (neighbours in a row complete each other's lines)
     uint32_t blocked;             // W = 2: the two intermediates are stored in 128-byte blocks of
                                   // 4 x 4 (row of one digit, row of the other) pairs, so that the kernel that reads
                                   // them strided touches whole cache lines instead of 32-byte segments
@@ -292,7 +293,9 @@ __device__ __forceinline__ void to_rows(TL& tile, V (&v)[16], uint32_t t, uint32
 template <int LQ, int VW>
 __device__ __forceinline__ uint32_t tile_of_block(uint32_t bid, uint32_t remap) {
     if (!remap) return bid;
-    constexpr uint32_t LG = (VW == 2 ? 4 : 5) - LQ;  // log2(tiles per 128-byte line)
+    // remap = 1: groups of the tiles that share a 128-byte line; remap >= 2: groups of 2^remap consecutive tiles (wide matrices: rows are
+    // not multiples of 128 bytes, so a tile's row segments straddle lines that its neighbours in the row complete)
+    const uint32_t LG = remap == 1 ? (VW == 2 ? 4u : 5u) - LQ : remap;
     const uint32_t xcd = bid & 7u, s = bid >> 3;
     return ((s >> LG) << (LG + 3)) | (xcd << LG) | (s & ((1u << LG) - 1u));
 }
@@ -349,10 +352,10 @@ __device__ __forceinline__ void scale_ladder(V (&v)[16], uint32_t c, uint32_t ph
 
 // K3 tiles of 2 row blocks over blocked input: blocks b and b + 8 of the grid share an XCD (round-robin dealing), give them the two
 // halves of one group of four row blocks (speed only: the result does not depend on placement)
-__device__ __forceinline__ uint32_t k3_tile_of_block(uint32_t bid, uint32_t pairs) {
-    if (!pairs) return bid;
+__device__ __forceinline__ uint32_t k3_tile_of_block(uint32_t bid, uint32_t lg) {  // lg = log2(consecutive tiles per XCD), 0 = as dealt
+    if (!lg) return bid;
     const uint32_t xcd = bid & 7u, s = bid >> 3;
-    return ((s >> 1) << 4) | (xcd << 1) | (s & 1u);
+    return ((s >> lg) << (lg + 3)) | (xcd << lg) | (s & ((1u << lg) - 1u));
 }
 // slot index -> (row group, column slot)
 __device__ __forceinline__ uint32_t slot_row(const NarrowArgs& a, uint32_t s) { return a.wsl != 0xffffffffu ? s >> a.wsl : s / a.spr; }

@@ -123,6 +123,45 @@ def cpu_baseline_wide(job):
             "seconds_estimated_whole_job": est, "lde_columns_equal_to_gpu": same, "leaf_digests_equal_to_gpu": same_d}
 
 
+def other_workloads():
+    """The default run (what the driver records) also carries SHORT runs of the other single-GPU BASELINE configs and of the
+    reference's own configuration, so that their numbers are in a driver-run record and not only in builder-run profiles:
+    each is this same script in a child process (`--no-cpu-baseline --no-extras`, few steps), its line condensed.  A child
+    that fails leaves its error text; the main line does not depend on them."""
+    import subprocess
+    runs = [("cfg3", ["--workload", "cfg3", "--steps", "2", "--warmup", "1"]),
+            ("cfg5", ["--workload", "cfg5", "--steps", "6", "--warmup", "2"]),
+            ("cfg2 under the reference's Keccak hashes", ["--hash", "keccak", "--steps", "6", "--warmup", "1"]),
+            ("the reference's own configuration (Keccak + hiding), 2^20 rows", ["--hash", "keccak", "--hiding", "--steps", "3", "--warmup", "1"])]
+    res = []
+    for label, extra in runs:
+        t0 = time.perf_counter()
+        entry = {"label": label, "command": "python bench.py " + " ".join(extra) + " --no-cpu-baseline --no-extras"}
+        try:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra + ["--no-cpu-baseline", "--no-extras"],
+                               capture_output=True, text=True, timeout=300)
+            lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+            if p.returncode != 0 or not lines:
+                entry["error"] = "exit code %d: %s" % (p.returncode, p.stderr.strip()[-300:])
+            else:
+                d = json.loads(lines[-1])
+                entry.update({k: d[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step") if k in d})
+                entry["workload"] = d["config"]["workload"]
+                r = d.get("roofline") or {}
+                entry["roofline"] = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_us", "algorithmic_bytes", "kernel")}
+                v = d.get("valu_roofline") or {}
+                if v:
+                    entry["valu_roofline"] = {k: v.get(k) for k in ("hash", "achieved", "frac", "instructions_per_permutation", "sustained_gperm_s",
+                                                                    "kernel_ceiling_gperm_s", "sustained_frac_of_kernel_ceiling")}
+                if "commit" in r:
+                    entry["roofline"]["commit"] = r["commit"]
+        except Exception as e:  # noqa: BLE001
+            entry["error"] = repr(e)
+        entry["wall_s"] = round(time.perf_counter() - t0, 1)
+        res.append(entry)
+    return res
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` with no launcher around it: start N fresh rank processes (one per GPU) with
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relay rank 0's JSON line, return the worst exit code.  This parent has
@@ -185,6 +224,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="independent proofs per rank per step")
     ap.add_argument("--threads", type=int, default=None, help="concurrent provers (host threads/streams) per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="default run only: skip the short runs of the other BASELINE configs that are added to the line as `other_workloads`")
     ap.add_argument("--hash", choices=["poseidon2", "keccak"], default="poseidon2",
                     help="poseidon2 = BASELINE.json's configuration (default); keccak = the hashes the reference itself wires")
     ap.add_argument("--hiding", action="store_true",
@@ -464,6 +505,10 @@ def run(args, job, dist, world, rank, local_rank, n_dev, backend, coll_dev, use_
         else:
             out["cpu_baseline"] = cpu_baseline_fib(args.log_height, job, 1 if args.hash == "keccak" else 0, hiding=args.hiding)
     job.close()
+    plain_default = (args.workload == "cfg2" and args.hash == "poseidon2" and not args.hiding and
+                     (args.log_height, args.log_blowup) == (defaults["log_height"], defaults["log_blowup"]))
+    if rank == 0 and world == 1 and not stub and plain_default and not args.no_extras:
+        out["other_workloads"] = other_workloads()
     if rank == 0:
         print(json.dumps(out))
     if use_dist:

@@ -26,14 +26,14 @@ say "LDE unit under rocprofv3 --kernel-trace --stats (the same command bench.py'
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_lde -o lde -- python3 $ROOT/tools/lde_unit_profile.py 20 1 > $OUT/lde_unit_cfg2.json 2> $OUT/prof_lde.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_lde24 -o lde24 -- python3 $ROOT/tools/lde_unit_profile.py 24 2 > $OUT/lde_unit_cfg3.json 2> $OUT/prof_lde24.err
 say "bench cfg2 under rocprofv3 --kernel-trace --stats: 4 provers, then a single prover"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -o bench -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_cfg2_under_rocprof.json 2> $OUT/prof_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench_1t -o bench1 -- python3 $ROOT/bench.py --steps 4 --warmup 1 --threads 1 --batch 8 --no-cpu-baseline > $OUT/bench_cfg2_1prover_under_rocprof.json 2> $OUT/prof_bench_1t.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -o bench -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $OUT/bench_cfg2_under_rocprof.json 2> $OUT/prof_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench_1t -o bench1 -- python3 $ROOT/bench.py --steps 4 --warmup 1 --threads 1 --batch 8 --no-cpu-baseline --no-extras > $OUT/bench_cfg2_1prover_under_rocprof.json 2> $OUT/prof_bench_1t.err
 cd $ROOT
 say "bench lines (un-profiled)"
 python3 bench.py > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err
 python3 bench.py --workload cfg3 > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err
 python3 bench.py --workload cfg5 > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err
-python3 bench.py --workload cfg4 --no-cpu-baseline > $OUT/bench_cfg4_1gpu.json 2> $OUT/bench_cfg4.err
+python3 bench.py --workload cfg4 --no-cpu-baseline --no-extras > $OUT/bench_cfg4_1gpu.json 2> $OUT/bench_cfg4.err
 python3 bench.py --hash keccak > $OUT/bench_keccak.json 2> $OUT/bench_keccak.err
 python3 bench.py --hash keccak --hiding > $OUT/bench_keccak_hiding.json 2> $OUT/bench_keccak_hiding.err
 say "2 ranks started by bench.py --gpus 2 over gloo on one GPU (NOT RCCL)"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 evidence, run on the GPU box from the repo root:  bash tools/collect_profiles_r03.sh
-# Everything lands under gpurun_out/r03_prof/; tools/_r03_copy_profiles.sh copies what is to be judged into profiles/.
+# Everything lands under gpurun_out/r03_prof/; tools/r03_copy_profiles.sh copies what is to be judged into profiles/.
 set -u
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/r03_prof

@@ -303,6 +303,20 @@ def main():
     return run(args, job, dist, world, rank, local_rank, n_dev, backend, coll_dev, use_dist, defaults, stub)
 
 
+class _DirectSink:
+    """Hands the prover threads the staging row of each proof (batch.ProofGatherer): the C prover writes the bytes there itself."""
+    direct = True
+
+    def __init__(self, put, rows):
+        self.put, self.rows = put, rows
+
+    def buffer(self, i):
+        return self.put.row_ptr(self.rows[i])
+
+    def done(self, i, length):
+        self.put.set(self.rows[i], i, length)
+
+
 class StubJob:
     """Stands in for FibAirJob under P3HIP_BENCH_STUB=1 (CPU tests of the CLI / launcher / collectives): a "proof" is 64
     bytes derived from the instance.  Nothing here is a measurement."""
@@ -407,7 +421,10 @@ def run(args, job, dist, world, rank, local_rank, n_dev, backend, coll_dev, use_
         mine = descriptors(k)
         rows = {i: r for r, (i, _, _) in enumerate(mine)}
         put, slot = coll_state["gatherer"].open(len(mine), coll_state["width"])
-        job.step_begin([(i, a) for i, a, _ in mine], lambda i, pf: put(rows[i], i, pf))
+        if stub or os.environ.get("P3HIP_BENCH_DIRECT_SINK", "1") != "1":
+            job.step_begin([(i, a) for i, a, _ in mine], lambda i, pf: put(rows[i], i, pf))
+        else:
+            job.step_begin([(i, a) for i, a, _ in mine], _DirectSink(put, rows))
         return slot
 
     def retire(slot):

@@ -65,6 +65,7 @@ _SIGS = {
                                             C.c_void_p]),
     "p3hip_fib_prover_prove": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.POINTER(C.c_uint8)),
                                          C.POINTER(C.c_size_t)]),
+    "p3hip_fib_prover_prove_into": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "p3hip_fib_prover_stage_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
     "p3hip_fib_prover_enqueue": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64]),
     "p3hip_fib_prover_finish": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]),

@@ -112,6 +112,10 @@ class ProofGatherer:
                 raise ValueError("proof of %d bytes does not fit the agreed slot of %d" % (len(proof), width))
             host[row, : len(proof)] = np.frombuffer(proof, dtype=np.uint8)
             meta[row] = (index, len(proof))
+        # direct form: the prover writes the proof into the staging row itself (FibAirProver.prove_into) — no bytes object, no copy
+        base, stride = ent["h"].data_ptr(), ent["h"].stride(0)
+        sink.row_ptr = lambda row: (base + row * stride, width)
+        sink.set = lambda row, index, length: meta.__setitem__(row, (index, length))
         return sink, ent
 
     def launch(self, ent):

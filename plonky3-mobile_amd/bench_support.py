@@ -62,6 +62,12 @@ class _Worker(threading.Thread):
                             i, a = jobs.get_nowait()
                         except queue.Empty:
                             break
+                        if getattr(sink, "direct", False):
+                            # the proof goes straight into the staging row of the step's gather: no bytes object on the way
+                            address, cap = sink.buffer(i)
+                            sink.done(i, self.prover.prove_into(a, a + 1, address, cap))
+                            done.append((i, None))
+                            continue
                         if not self.ahead:
                             emit(i, self.prover.prove(a, a + 1))
                             continue

@@ -495,6 +495,18 @@ int p3hip_fib_prover_prove(p3hip_fib_prover_t* prover, uint64_t a, uint64_t b, c
     });
 }
 
+int p3hip_fib_prover_prove_into(p3hip_fib_prover_t* prover, uint64_t a, uint64_t b, uint8_t* out, size_t cap, size_t* proof_len) {
+    return guarded([&]() -> int {
+        if (!prover || !out || !proof_len) return fail(ERR_BAD_ARG, "fib_prover_prove_into: null argument");
+        int rc = prover->hiding ? prover->hiding->prove(a, b, &prover->last) : prover->plain->prove(a, b, &prover->last);
+        if (rc) return rc;
+        *proof_len = prover->last.size();
+        if (prover->last.size() > cap) return fail(ERR_BAD_ARG, "fib_prover_prove_into: the proof needs " + std::to_string(prover->last.size()) + " bytes");
+        memcpy(out, prover->last.data(), prover->last.size());
+        return OK;
+    });
+}
+
 int p3hip_fib_prover_enqueue(p3hip_fib_prover_t* prover, uint64_t a, uint64_t b) {
     return guarded([&]() -> int {
         if (!prover) return fail(ERR_BAD_ARG, "fib_prover_enqueue: null argument");

@@ -66,6 +66,13 @@ class FibAirProver:
         _lib.check(_lib.lib().p3hip_fib_prover_prove(self._h, a, b, C.byref(out), C.byref(n)))
         return C.string_at(out, n.value)
 
+    def prove_into(self, a, b, address, cap):
+        """Proves and writes the bytes at `address` (an int: e.g. the data pointer of a pinned staging row of `cap` bytes);
+        returns the proof's length.  No Python bytes object is made: the C call runs without the GIL."""
+        n = C.c_size_t()
+        _lib.check(_lib.lib().p3hip_fib_prover_prove_into(self._h, a, b, C.c_void_p(address), cap, C.byref(n)))
+        return n.value
+
     def enqueue(self, a, b):
         """Queues the proof's launches and returns at once (at most two proofs in flight; not for the hiding prover)."""
         _lib.check(_lib.lib().p3hip_fib_prover_enqueue(self._h, a, b))

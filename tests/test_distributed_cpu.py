@@ -125,8 +125,17 @@ def _worker_pipelined(rank, world, port, q):
     def issue(step):
         mine = descriptors(step)
         put, slot = g.open(len(mine), width)
-        ths = [threading.Thread(target=lambda r=r, i=i, a=a, b=b: put(r, i, b"S%d:%d:%d:%d" % (step, i, a, b) * (1 + i % 3)))
-               for r, (i, a, b) in enumerate(mine)]
+        def write(r, i, a, b):
+            data = b"S%d:%d:%d:%d" % (step, i, a, b) * (1 + i % 3)
+            if step % 2 == 0:
+                put(r, i, data)
+            else:  # the direct form bench.py uses: the prover writes into the staging row itself (FibAirProver.prove_into)
+                import ctypes
+                address, cap = put.row_ptr(r)
+                assert cap == width and len(data) <= cap
+                ctypes.memmove(address, data, len(data))
+                put.set(r, i, len(data))
+        ths = [threading.Thread(target=write, args=(r, i, a, b)) for r, (i, a, b) in enumerate(mine)]
         [t.start() for t in ths]
         return ths, slot
 

@@ -249,3 +249,20 @@ def test_grind_search_continues_after_an_empty_first_range(p3, oracle, hash, mon
         assert pr.finish() == oracle.prove_fib_air(a - 1, a, 9, ofp, hash=kind)
     assert pr.finish() == oracle.prove_fib_air(3, 4, 9, ofp, hash=kind)
     pr.close()
+
+
+def test_prove_into_writes_the_same_bytes(p3, oracle):
+    """p3hip_fib_prover_prove_into: the proof written into a caller's buffer (bench.py: the pinned staging row of the step's gather)
+    equals the bytes prove() returns; a buffer that is too small is refused with the needed size, nothing is truncated."""
+    import ctypes as C
+    import torch
+    gfp, ofp = _fp(p3, oracle, 1, 0, 10, 6)
+    pr = p3.FibAirProver(11, params=gfp)
+    ref = pr.prove(5, 6)
+    buf = torch.zeros(len(ref) + 64, dtype=torch.uint8).pin_memory()
+    n = pr.prove_into(5, 6, buf.data_ptr(), buf.numel())
+    assert n == len(ref) and bytes(buf[:n].numpy()) == ref == oracle.prove_fib_air(5, 6, 11, ofp)
+    assert not buf[n:].any()
+    with pytest.raises(p3.P3HipError, match="needs %d bytes" % len(ref)):
+        pr.prove_into(5, 6, buf.data_ptr(), 100)
+    pr.close()

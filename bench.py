@@ -238,7 +238,7 @@ def main():
     if env_world is not None and args.gpus > 1 and int(env_world) != args.gpus:
         print("bench.py: --gpus %d contradicts WORLD_SIZE=%s" % (args.gpus, env_world), file=sys.stderr)
         sys.exit(2)
-    defaults = {"cfg2": dict(log_height=20, log_blowup=1, batch=32, threads=4, steps=20, warmup=2),
+    defaults = {"cfg2": dict(log_height=20, log_blowup=1, batch=32, threads=4, steps=40, warmup=2),
                 "cfg4": dict(log_height=20, log_blowup=1, batch=None, threads=4, steps=10, warmup=1),
                 "cfg3": dict(log_height=24, log_blowup=2, batch=4, threads=2, steps=3, warmup=1),
                 "cfg5": dict(log_height=16, log_blowup=1, batch=1, threads=1, steps=10, warmup=2)}[args.workload]

@@ -155,6 +155,55 @@ __global__ void __launch_bounds__(256) leaf_hash_f64_kernel(const uint32_t* mat,
     for (int i = 0; i < 8; i++) d[i] = p2f::store_elem(s[i], smk);
     store_digest(digests + r * 8, d);
 }
+// WIDE rows (BASELINE configs[4]: 2633 words per row): in the kernel above a lane walks its own row, so every load instruction of a
+// wave touches 64 lines 10 KB apart.  Here the workgroup's 256 rows are staged through LDS in chunks of 32 words per row, loaded
+// 2 rows x 128 contiguous bytes per wave-instruction (coalesced), handed over transposed (row stride 36 words: the 16-byte reads of
+// 16 consecutive lanes cover all 64 banks once), the next chunk in flight while four permutations absorb the current one.
+constexpr uint32_t LEAF_WIDE_CHUNK = 32, LEAF_WIDE_STRIDE = 36;
+__global__ void __launch_bounds__(256) leaf_hash_f64_wide_kernel(const uint32_t* mat, uint32_t width, uint64_t n_rows, uint32_t* digests) {
+    __shared__ __attribute__((aligned(16))) uint32_t tile[256 * LEAF_WIDE_STRIDE];
+    const uint32_t tid = threadIdx.x, col = tid & 31u, rsub = tid >> 5;  // loader role: 8 row groups x 32 columns
+    const uint64_t r0 = (uint64_t)blockIdx.x * 256u, r = r0 + tid;
+    double s[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = 0.0;
+    uint32_t pre[32];
+    auto fetch = [&](uint32_t c0) {
+#pragma unroll
+        for (uint32_t i = 0; i < 32; i++) {
+            const uint64_t row = r0 + rsub + 8u * i;
+            pre[i] = (row < n_rows && c0 + col < width) ? mat[row * width + c0 + col] : 0u;
+        }
+    };
+    fetch(0);
+    for (uint32_t c0 = 0; c0 < width; c0 += LEAF_WIDE_CHUNK) {
+        __syncthreads();  // the previous chunk has been read by every lane
+#pragma unroll
+        for (uint32_t i = 0; i < 32; i++) tile[(rsub + 8u * i) * LEAF_WIDE_STRIDE + col] = pre[i];
+        __syncthreads();
+        if (c0 + LEAF_WIDE_CHUNK < width) fetch(c0 + LEAF_WIDE_CHUNK);  // in flight during the four permutations below
+        const uint4* mine = reinterpret_cast<const uint4*>(tile + tid * LEAF_WIDE_STRIDE);
+#pragma unroll 1
+        for (uint32_t k = 0; k < LEAF_WIDE_CHUNK && c0 + k < width; k += 8) {
+            const uint4 a = mine[k / 4], b = mine[k / 4 + 1];
+            const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (c0 + k + i < width) s[i] = p2f::load_elem(w[i]);
+            p2f::permute(s);
+            if (c0 + k + 8 < width) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) s[i] = p2f::reduce(s[i]);
+            }
+        }
+    }
+    if (r >= n_rows) return;
+    uint32_t d[8];
+    const p2f::MagicRegs smk = p2f::magic_regs();
+#pragma unroll
+    for (int i = 0; i < 8; i++) d[i] = p2f::store_elem(s[i], smk);
+    store_digest(digests + r * 8, d);
+}
 // the same sponge over the CONCATENATED rows of several matrices of one height (the (matrix, salt) pairs of the hiding
 // MMCS, or any multi-matrix commitment): element k of the row comes from the matrix whose column range holds k
 __global__ void __launch_bounds__(256) leaf_hash_f64_rowset_kernel(RowSet rs, uint64_t n_rows, uint32_t* digests) {
@@ -564,6 +613,10 @@ static RowSet make_rowset(const Tree& t, uint64_t h) {
     return rs;
 }
 
+static bool leaf_wide_enabled() {  // P3HIP_LEAF_WIDE=0: the one-row-per-lane kernel for wide rows too
+    static const bool on = [] { const char* e = getenv("P3HIP_LEAF_WIDE"); return !e || atoi(e) != 0; }();
+    return on;
+}
 static bool use_f64_tree() {
     static int v = [] { const char* e = getenv("P3HIP_TREE_F64"); return e ? atoi(e) : 1; }();
     return v != 0;
@@ -674,6 +727,9 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
         if (rs.count == 1 && maxh < COOP_MAX && maxh * 16 <= 0x7fffffffull) {
             hipLaunchKernelGGL(leaf_coop_kernel, dim3((uint32_t)((maxh * 16 + 255) / 256)), dim3(256), 0, stream, rs.ptr[0],
                                rs.width[0], (uint32_t)maxh, t->layers);
+        } else if (rs.count == 1 && use_f64_tree() && rs.width[0] >= 64 && leaf_wide_enabled()) {
+            hipLaunchKernelGGL(leaf_hash_f64_wide_kernel, dim3((uint32_t)((maxh + 255) / 256)), dim3(256), 0, stream, rs.ptr[0],
+                               rs.width[0], maxh, t->layers);
         } else if (rs.count == 1 && use_f64_tree()) {
             hipLaunchKernelGGL(leaf_hash_f64_kernel, dim3((uint32_t)((maxh + 255) / 256)), dim3(256), 0, stream, rs.ptr[0],
                                rs.width[0], maxh, t->layers);

@@ -81,6 +81,22 @@ def test_mmcs_headline_size(p3, oracle):
         assert oracle.mmcs_verify_batch(root, [(1 << 21, 2)], idx, rows[0], path)
 
 
+@pytest.mark.parametrize("h,w", [(4096, 64), (4096, 77), (8192, 333), (16384, 65), (4096, 2633)])
+def test_wide_rows_leaf_layer_vs_oracle(p3, oracle, h, w):
+    """Rows of >= 64 words take the LDS-staged leaf kernel (leaf_hash_f64_wide_kernel: 32-word chunks per row, partial last
+    chunk, widths that are not multiples of 8 or 32): every leaf digest and the root against the oracle's sponge."""
+    rng = np.random.default_rng(100 * w + h)
+    m = _rand(rng, h, w)
+    root, tree = p3.MerkleTreeMmcs().commit([m])
+    leaves = tree.digest_layers()[0]
+    rows = np.concatenate([np.arange(0, 300), rng.integers(0, h, 200), np.arange(h - 260, h)])
+    exp = np.stack([oracle.hash_row(m[r]) for r in rows])
+    assert np.array_equal(leaves[rows], exp)
+    oroot, _ = oracle.mmcs_commit([m])
+    assert np.array_equal(root, oroot)
+    tree.free()
+
+
 def test_mmcs_rejects_bad_input(p3):
     mm = p3.MerkleTreeMmcs()
     with pytest.raises(p3.P3HipError):

@@ -224,7 +224,7 @@ class FibAirJob:
         L = _lib.lib()
         kind = 1 if self.hash == "keccak" else 0
 
-        def commit_ms(rows, reps):
+        def commit_ms(rows, reps, best=False):
             x = torch.randint(0, 0x78000001, (rows, 2), dtype=torch.int32, device="cuda")
             layers = torch.empty((L.p3hip_mmcs_layer_words(rows),), dtype=torch.int32, device="cuda")
             ptrs, hs, ws = (C.c_void_p * 1)(x.data_ptr()), (C.c_size_t * 1)(rows), (C.c_size_t * 1)(2)
@@ -233,11 +233,13 @@ class FibAirJob:
                 h = C.c_void_p()
                 _lib.check(L.p3hip_mmcs_commit_into_dev(kind, ptrs, hs, ws, 1, C.c_void_p(layers.data_ptr()), C.byref(h), _stream_ptr()))
                 L.p3hip_mmcs_free(h)
-            return self._time(commit, reps)
+            if not best:
+                return self._time(commit, reps)
+            return min(self._time(commit, 1) for _ in range(reps))  # a ceiling: the fastest of `reps` timed commits
         ms = commit_ms(n, 5)
         perms = 2 * n - 1
         big_rows = 1 << 24  # a tree whose layers fill the chip for many workgroup generations: the kernels' own ceiling
-        ms_big = commit_ms(big_rows, 2)
+        ms_big = commit_ms(big_rows, 4, best=True)
         hname = "Keccak-f[1600]" if kind else "Poseidon2-BabyBear-16"
         out = {"bound": "valu", "hash": hname, "unit": "Gperm/s",
                "kernel": "the hash layers as the prover runs them: one commit of 2^%d x 2 into pre-allocated layers (%s)" % (

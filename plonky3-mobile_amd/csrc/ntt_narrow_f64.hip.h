@@ -1,17 +1,21 @@
 // The three-launch narrow coset LDE of ntt_narrow.hip.h with its butterflies in DOUBLE PRECISION integer arithmetic.
 //
-// Why: the integer kernels are VALU-bound at 12 instructions per butterfly (add/sub/min, sub/add, and the seven-op
-// Montgomery product) and run at 1-2 waves per SIMD, where every instruction costs the same ~5-6 cycles whatever its
-// type (profiles/r01_microbench2_valu_issue_rates.txt): what counts is the NUMBER of instructions.  BabyBear has one
-// spare bit in a 32-bit word (4P > 2^32), so neither Harvey's lazy butterflies nor a signed lazy representation fit; in
-// fp64 they do: a lane keeps integers |v| < 2^44 congruent to the Montgomery WORDS (the transform is linear, so the
-// words themselves are transformed, with CANONICAL twiddles), a modular add / sub is ONE v_add_f64 with no reduction for
-// a whole 12-stage digit, and the product is the four-op magic-number form of poseidon2_f64.hip.h:
+// Why it was built: the integer kernels spend 12 VALU instructions per butterfly (add/sub/min, sub/add, and the seven-op Montgomery
+// product).  BabyBear has one spare bit in a 32-bit word (4P > 2^32), so neither Harvey's lazy butterflies nor a signed lazy
+// representation fit; in fp64 they do: a lane keeps integers |v| < 2^44 congruent to the Montgomery WORDS (the transform is linear, so
+// the words themselves are transformed, with CANONICAL twiddles), a modular add / sub is ONE v_add_f64 with no reduction for a whole
+// 12-stage digit, and the product is the four-op magic-number form of poseidon2_f64.hip.h:
 //     (x, y) -> (x + y, (x - y) * w)        6 instructions instead of 12.
-// Conversions: one v_cvt_f64_u32 per loaded word; 3 instructions per stored word when the value comes out of a
-// product (|r| <= P/2 + 1: convert, add P, min), 4 when it does not (floor-quotient reduction, below).  Between the
-// register rounds the tile is exchanged through LDS as doubles (one 8-byte plane per column of the lane's vector, the
-// same padded layout and bank analysis as the uint2 tiles of the integer kernels).
+// Conversions: one v_cvt_f64_u32 per loaded word; 3 instructions per stored word when the value comes out of a product
+// (|r| <= P/2 + 1: convert, add P, min), 4 when it does not (floor-quotient reduction, below).  Between the register rounds the tile
+// is exchanged through LDS as doubles (one 8-byte plane per column of the lane's vector, the same padded layout and bank analysis
+// as the uint2 tiles of the integer kernels), or — XW kernels — as words (five more instructions per element and hand-over, the
+// integer kernels' LDS footprint); the last hand-over of K1 / K3 is always on words.
+//
+// What it bought (profiles/r03_pmc_lde_valu.json, r03_lde_f64_vs_int.txt): a third fewer VALU instructions
+// per wave and 2-8 % of the unit's time up to 2^20 rows — the unit is a chain of unoverlapped phases, and the hand-overs of doubles
+// cost what the rounds save.  From 2^21 rows on these kernels LOSE: 64 VGPRs for a lane's 16 x 2 points halve the waves per SIMD of
+// kernels that live on them.  lde_narrow therefore uses them up to 2^19 rows and at 2^20 x 2 only.
 //
 // Results are bit-identical to the integer kernels (same data layouts in HBM, same intermediates T and dst).
 // Stage semantics: backend_vulkan.rs:881-942 (DIF form), twiddle layout :977-996.

@@ -12,8 +12,10 @@
 //     RUN/W consecutive rows), later passes are in place with a pre-twiddle w_{2^(s0+b)}^(rev(pt)*lo).
 //   DIF plan (natural in -> bit-reversed or natural out): top digit first, post-twiddle after the tile
 //     transform; zero padding and the coset/1/N scaling are folded into the first pass's loads.
-//   Narrow plan (ntt_narrow.hip.h): the coset LDE of matrices up to 16 columns wide, bit-reversed output, 2^16..2^24
-//     rows — the fib_air trace and quotient commitments — as two digits per direction in three launches.
+//   Narrow plan (ntt_narrow.hip.h, ntt_narrow_f64.hip.h): the coset LDE of matrices up to 16 columns wide (W = 2, 4, 6, 8, 16),
+//     bit-reversed output, 2^16..2^24 rows — the fib_air trace / quotient / hiding commitments — as two digits per direction
+//     in three launches (two when the input is coefficients); the same plan with 128-byte tile rows for matrices of any
+//     width >= 64 at 2^16 rows (BASELINE configs[4]).  Integer or fp64 butterflies, chosen per shape from measurement.
 //
 // Row-major H x W matrices of Montgomery words, exactly the buffers the reference uploads
 // (backend_vulkan.rs:2002-2005).  Stage semantics inside a tile are those of cpu_stage_u32_in_place

@@ -1,4 +1,5 @@
-// Three-launch coset LDE for NARROW matrices (W = 2, 4, 8 or 16 columns: the fib_air trace and quotient shapes).
+// Three-launch coset LDE for NARROW matrices (W = 2, 4, 6, 8 or 16 columns: the fib_air trace, quotient and hiding shapes) and, with
+// 128-byte tile rows, for WIDE ones (any width >= 64 at 2^16 rows).
 //
 // The general plans (ntt.hip / ntt_fast.hip.h) move one 32-bit word per lane and cut 2^n rows into three 6-8 stage
 // digits per direction: five launches for 2^20 -> 2^21, every one re-reading and re-writing the matrix.  Here the

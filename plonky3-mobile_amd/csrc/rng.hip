@@ -10,10 +10,14 @@
 //     of that chunk index's set bits and walks J_0 to the next 63, each product done by the whole wave in a
 //     lane-interleaved basis (lane l owns four rows; the four ballots of the parity bits ARE the product: ~80
 //     instructions, no shuffle, instead of ~3000 for one lane);
-//   - pass 1 counts the accepted draws of every chunk, a one-workgroup scan turns the counts into output offsets,
-//     pass 2 replays the chunks and writes the accepted values to their places; the lane that writes the n-th value
-//     also writes the generator state right after that draw back to the stream, so the next fill continues exactly
-//     where a host loop would.
+//   - pass 1 generates every chunk ONCE: it counts the accepted draws and keeps all 256 raw candidates of the chunk, written
+//     through a 64 x 32 LDS tile so that each chunk's candidates leave in whole 128-byte pieces; a two-level scan turns the
+//     counts into output offsets; pass 2 (one wave per chunk, 16-byte loads) compacts the accepted candidates to their places
+//     with a wave scan — neighbours write neighbours; the lane that holds the n-th value replays its chunk from the saved state
+//     up to that draw and writes the generator state back to the stream, so the next fill continues exactly where a host loop
+//     would.  (First form, P3HIP_RNG_TWO_PASS=1: pass 1 only counted and pass 2 generated every draw again, each lane writing
+//     4-byte words 960 bytes from its neighbour's: 31 instead of 50 instructions per draw and coalesced stores bought the
+//     hiding bench 3.4 %.)
 // Nothing synchronises with the host.  A fill that runs out of raw draws (probability far below 2^-100 with the margin
 // used) raises the error word instead of producing a short stream.
 #include "bb31.hip.h"
@@ -247,6 +251,86 @@ __global__ void __launch_bounds__(256) rng_pass2_kernel(DevRng* st, const uint64
     if (t + 1 == n_chunks) atomicOr(err, 1u);  // ran out of raw draws (never, with the margin of rng_fill_field)
 }
 
+// ---- one generation per draw (the default): pass 1 keeps the RAW 31-bit candidates, pass 2 only compacts them ----
+// Pass 1 as above (jump, walk, count), but every candidate is kept: the wave's 64 lanes (= 64 chunks) produce one candidate each
+// per step; 32 steps fill a 64 x 32 tile in LDS, which goes out transposed — lanes 0..31 write 128 contiguous bytes of one
+// chunk, lanes 32..63 of the next — so raw[chunk][0..256) is written in whole 128-byte pieces instead of 4-byte words 1 KB apart.
+__global__ void __launch_bounds__(64) rng_gen_kernel(const DevRng* st, const uint64_t* __restrict__ jump, uint32_t n_chunks, uint32_t n_bits,
+                                                     uint64_t* states, uint32_t* counts, uint32_t* raw) {
+    __shared__ uint32_t tile[64 * 33];
+    const uint32_t lane = threadIdx.x, first = blockIdx.x * 64u, t = first + lane;
+    uint64_t cur[4] = {st->s[0], st->s[1], st->s[2], st->s[3]};
+    to_interleaved(cur);
+    const LaneRows j0 = load_rows(jump);
+    for (uint32_t k = 6; k < n_bits; k++)
+        if ((first >> k) & 1u) wave_matvec(load_rows(jump + (size_t)k * 256 * 4), cur);  // uniform branch
+    uint64_t s[4] = {cur[0], cur[1], cur[2], cur[3]};
+    const uint32_t last = n_chunks - first < 64u ? n_chunks - first : 64u;  // chunks of this wave
+    for (uint32_t i = 1; i < last; i++) {
+        wave_matvec(j0, cur);
+        if (lane == i) { s[0] = cur[0]; s[1] = cur[1]; s[2] = cur[2]; s[3] = cur[3]; }
+    }
+    from_interleaved(s);
+    if (t < n_chunks) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) states[(size_t)t * 4 + w] = s[w];
+    }
+    uint32_t cnt = 0;
+    const uint32_t half = lane >> 5, col = lane & 31u;
+    for (uint32_t round = 0; round < RNG_CHUNK / 32; round++) {
+#pragma unroll 4
+        for (uint32_t i = 0; i < 32; i++) {
+            const uint32_t v = (uint32_t)(xoshiro_next(s) >> 32) >> 1;
+            cnt += v < bb::P ? 1u : 0u;
+            tile[lane * 33 + i] = v;
+        }
+        __syncthreads();  // one wave per workgroup: orders the tile's writes before its transposed reads
+        for (uint32_t c = 0; c < 64; c += 2) {  // chunk c on lanes 0..31, chunk c + 1 on lanes 32..63
+            const uint32_t ch = c + half;
+            if (ch < last) raw[((size_t)(first + ch) << RNG_CHUNK_LOG) + round * 32 + col] = tile[ch * 33 + col];
+        }
+        __syncthreads();
+    }
+    if (t < n_chunks) counts[t] = cnt;
+}
+// Pass 2: one wave per chunk.  Lane l holds candidates 4l .. 4l+3 (one 16-byte load), a wave scan of the acceptance counts gives
+// every accepted value its place, neighbours write neighbours.  The lane that holds the n-th element of the fill replays its chunk
+// from the saved state up to that draw and leaves the generator there: the next fill continues where a host loop would.
+__global__ void __launch_bounds__(256) rng_compact_kernel(DevRng* st, const uint64_t* states, const uint32_t* offsets, const uint32_t* bsum,
+                                                          uint32_t n_chunks, const uint32_t* raw, uint32_t* out, uint64_t n, uint32_t* err) {
+    const uint32_t lane = threadIdx.x & 63u, c = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (c >= n_chunks) return;
+    const uint64_t base = (uint64_t)offsets[c] + bsum[c / SCAN_TILE];
+    if (base >= n) return;  // the stream was complete before this chunk
+    const uint4 v4 = reinterpret_cast<const uint4*>(raw + ((size_t)c << RNG_CHUNK_LOG))[lane];
+    const uint32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
+    uint32_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) mine += v[k] < bb::P ? 1u : 0u;
+    uint32_t inc = mine;  // inclusive scan over the wave
+#pragma unroll
+    for (uint32_t off = 1; off < 64; off <<= 1) {
+        const uint32_t u = (uint32_t)__shfl_up((int)inc, off, 64);
+        if (lane >= off) inc += u;
+    }
+    uint64_t pos = base + (inc - mine);
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        if (v[k] < bb::P) {
+            if (pos < n) out[pos] = v[k];
+            if (pos + 1 == n) {  // the n-th element: replay this chunk up to raw draw 4 lane + k
+                uint64_t s[4] = {states[(size_t)c * 4], states[(size_t)c * 4 + 1], states[(size_t)c * 4 + 2], states[(size_t)c * 4 + 3]};
+                for (uint32_t i = 0; i <= 4 * lane + k; i++) (void)xoshiro_next(s);
+#pragma unroll
+                for (int w = 0; w < 4; w++) st->s[w] = s[w];
+            }
+            pos++;
+        }
+    }
+    const uint32_t total = (uint32_t)__shfl((int)inc, 63, 64);
+    if (c + 1 == n_chunks && lane == 0 && base + total < n) atomicOr(err, 1u);  // ran out of raw draws (never, with the margin used)
+}
+
 __global__ void rng_set_kernel(DevRng* st, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
     st->s[0] = a; st->s[1] = b; st->s[2] = c; st->s[3] = d;
 }
@@ -267,7 +351,8 @@ bool rng_fill_supported(uint64_t n) { return (fill_chunks(n) >> RNG_MAX_JUMP) ==
 int rng_workspace_words(uint64_t n_max, size_t* words) {
     const uint64_t chunks = fill_chunks(n_max);
     if (chunks >> RNG_MAX_JUMP) return fail(ERR_BAD_ARG, "rng: fill too large");
-    *words = (size_t)chunks * 8 + (size_t)chunks + (size_t)(chunks / SCAN_TILE + 1) + 16;  // states (4 x u64) + counts + block totals
+    // states (4 x u64) + counts + block totals + the raw candidates of every chunk (one-generation fill)
+    *words = (size_t)chunks * 8 + (size_t)chunks + (size_t)(chunks / SCAN_TILE + 1) + 16 + ((size_t)chunks << RNG_CHUNK_LOG) + 4;
     return OK;
 }
 
@@ -289,10 +374,25 @@ int rng_fill_field(Context& cx, hipStream_t stream, DevRng* st, uint32_t* out, u
     uint64_t* states = reinterpret_cast<uint64_t*>(workspace);
     uint32_t* counts = workspace + (size_t)chunks * 8;
     const uint32_t blocks = (chunks + 255) / 256;
-    hipLaunchKernelGGL(rng_pass1_kernel, dim3((chunks + 63) / 64), dim3(64), 0, stream, st, cx.rng_jump, chunks, n_bits, states, counts);
-    P3_HIP(hipGetLastError());
+    // P3HIP_RNG_TWO_PASS=1: the first form (every draw generated twice: counted, then written by its own lane)
+    static const bool two_pass = [] { const char* e = getenv("P3HIP_RNG_TWO_PASS"); return e && atoi(e) != 0; }();
     const uint32_t tiles = (chunks + SCAN_TILE - 1) / SCAN_TILE;
     uint32_t* bsum = counts + chunks;
+    if (!two_pass) {
+        // raw candidates behind the block totals, 16-byte aligned
+        uint32_t* raw = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(bsum + tiles + 1) + 15u) & ~(uintptr_t)15u);
+        hipLaunchKernelGGL(rng_gen_kernel, dim3((chunks + 63) / 64), dim3(64), 0, stream, st, cx.rng_jump, chunks, n_bits, states, counts, raw);
+        P3_HIP(hipGetLastError());
+        hipLaunchKernelGGL(rng_scan_tiles_kernel, dim3(tiles), dim3(256), 0, stream, counts, chunks, bsum);
+        P3_HIP(hipGetLastError());
+        hipLaunchKernelGGL(rng_scan_kernel, dim3(1), dim3(1024), 0, stream, bsum, tiles);
+        P3_HIP(hipGetLastError());
+        hipLaunchKernelGGL(rng_compact_kernel, dim3((chunks + 3) / 4), dim3(256), 0, stream, st, states, counts, bsum, chunks, raw, out, n, err);
+        P3_HIP(hipGetLastError());
+        return OK;
+    }
+    hipLaunchKernelGGL(rng_pass1_kernel, dim3((chunks + 63) / 64), dim3(64), 0, stream, st, cx.rng_jump, chunks, n_bits, states, counts);
+    P3_HIP(hipGetLastError());
     hipLaunchKernelGGL(rng_scan_tiles_kernel, dim3(tiles), dim3(256), 0, stream, counts, chunks, bsum);
     P3_HIP(hipGetLastError());
     hipLaunchKernelGGL(rng_scan_kernel, dim3(1), dim3(1024), 0, stream, bsum, tiles);

@@ -313,21 +313,31 @@ __global__ void __launch_bounds__(256) rng_compact_kernel(DevRng* st, const uint
         const uint32_t u = (uint32_t)__shfl_up((int)inc, off, 64);
         if (lane >= off) inc += u;
     }
-    uint64_t pos = base + (inc - mine);
+    // accepted values to their rank in the wave's 256-word LDS row, then out in rank order: lane l writes ranks l, l + 64, ... so
+    // every store instruction of the wave covers 256 contiguous bytes
+    __shared__ uint32_t packed[4][RNG_CHUNK];
+    uint32_t* row = packed[threadIdx.x >> 6];
+    uint32_t rank = inc - mine;
 #pragma unroll
     for (uint32_t k = 0; k < 4; k++) {
         if (v[k] < bb::P) {
-            if (pos < n) out[pos] = v[k];
-            if (pos + 1 == n) {  // the n-th element: replay this chunk up to raw draw 4 lane + k
+            row[rank] = v[k];
+            if (base + rank + 1 == n) {  // the n-th element: replay this chunk up to raw draw 4 lane + k
                 uint64_t s[4] = {states[(size_t)c * 4], states[(size_t)c * 4 + 1], states[(size_t)c * 4 + 2], states[(size_t)c * 4 + 3]};
                 for (uint32_t i = 0; i <= 4 * lane + k; i++) (void)xoshiro_next(s);
 #pragma unroll
                 for (int w = 0; w < 4; w++) st->s[w] = s[w];
             }
-            pos++;
+            rank++;
         }
     }
     const uint32_t total = (uint32_t)__shfl((int)inc, 63, 64);
+    __builtin_amdgcn_wave_barrier();  // the row belongs to this wave alone: LDS operations of one wave complete in order
+#pragma unroll
+    for (uint32_t i = 0; i < RNG_CHUNK; i += 64) {
+        const uint32_t idx = i + lane;
+        if (idx < total && base + idx < n) out[base + idx] = row[idx];
+    }
     if (c + 1 == n_chunks && lane == 0 && base + total < n) atomicOr(err, 1u);  // ran out of raw draws (never, with the margin used)
 }
 

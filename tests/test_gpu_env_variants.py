@@ -22,7 +22,7 @@ VARIANTS = [
     {"P3HIP_NTT_NARROW_F64": "7", "P3HIP_NTT_NARROW_F64_TILES": "1", "P3HIP_NTT_NARROW_VW": "2"},
     {"P3HIP_NTT_NARROW_F64": "5", "P3HIP_NTT_NARROW_F64_TILES": "2", "P3HIP_NTT_NARROW_VW": "1", "P3HIP_NTT_NARROW_COSSPLIT": "1"},
     {"P3HIP_NTT_NARROW_F64": "7", "P3HIP_NTT_NARROW_F64_XW": "1", "P3HIP_VARIANT_BIG_LDE": "1"},  # fp64 rounds, hand-overs on words
-    {"P3HIP_RNG_TWO_PASS": "1", "P3HIP_LEAF_WIDE": "0"},                    # first forms of the RNG fill and of the wide-row leaf kernel
+    {"P3HIP_RNG_TWO_PASS": "1", "P3HIP_LEAF_WIDE": "0", "P3HIP_HIDING_BARY_SPLIT": "1"},                    # first forms of the RNG fill and of the wide-row leaf kernel
     {"P3HIP_NTT_NARROW_BLOCKED12": "0", "P3HIP_NTT_NARROW_K3_LQ1": "1", "P3HIP_NTT_NARROW_WIDE": "0", "P3HIP_VARIANT_BIG_LDE": "1"},
 ]
 

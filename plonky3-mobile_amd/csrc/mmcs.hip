@@ -679,7 +679,10 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
     // digests per workgroup of the 16-lane cooperative Poseidon2 levels kernel: 2^5 = four waves, five levels per launch (2^7, sixteen
     // waves on one CU and seven levels, measured 1.5 % slower at four provers)
     static const uint32_t COOP_CHUNK_LOG = [] { const char* e = getenv("P3HIP_COOP_CHUNK_LOG"); int v = e ? atoi(e) : 5; return (uint32_t)(v < 3 ? 3 : (v > 7 ? 7 : v)); }();
-    static const uint64_t KCOOP_IN = [] { const char* e = getenv("P3HIP_KECCAK_COOP_MAX_LOG"); int v = e ? atoi(e) : 12; return v <= 0 ? (uint64_t)0 : (uint64_t)1 << (v > 15 ? 15 : v); }();
+    // Cooperative Keccak levels for layers of <= 2^10 digests: one state per wave spends ~13x the lane-instructions of the per-lane form,
+    // and with four provers VALU is what the chip is short of (2^12: 624.6 proofs/s, 2^11: 633, 2^10: 647, 2^9: 636 in the Keccak bench;
+    // the hiding bench does not care; a single proof's latency prefers 12: +0.2 ms at 10)
+    static const uint64_t KCOOP_IN = [] { const char* e = getenv("P3HIP_KECCAK_COOP_MAX_LOG"); int v = e ? atoi(e) : 10; return v <= 0 ? (uint64_t)0 : (uint64_t)1 << (v > 15 ? 15 : v); }();
     // one-state-per-lane levels kernel: digests per workgroup.  A level costs one permutation's issue time (~9 us) per
     // wave a SIMD holds, so ONE wave per workgroup (128 digests) spreads a layer of <= 2^15 digests over the whole chip;
     // 2048 (sixteen waves on one CU) was 25 us per level
@@ -694,7 +697,7 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
             uint64_t len = t->layer_len[l];
             RowSet rs = make_rowset(*t, len);
             if (len < COOP_MAX && !rs.count) {
-                // as many injection-free levels as one launch may take.  Layers of <= 2^12 digests (P3HIP_KECCAK_COOP_MAX_LOG,
+                // as many injection-free levels as one launch may take.  Layers of <= 2^10 digests (P3HIP_KECCAK_COOP_MAX_LOG,
                 // 0 = never) go through the lane-cooperative kernel, 2^P3HIP_KECCAK_COOP_CHUNK_LOG digests per workgroup; above that one state
                 // per lane, chunks of up to 2048 digests per workgroup, stopping where the cooperative kernel takes over
                 const uint64_t n_in = t->layer_len[l - 1];

@@ -16,6 +16,7 @@ VARIANTS = [
     {"P3HIP_COOP_MAX_LOG": "8", "P3HIP_COOP_CHUNK_LOG": "3"},
     {"P3HIP_KECCAK_COOP_MAX_LOG": "0", "P3HIP_KECCAK_LANE_CHUNK_LOG": "11"},  # no cooperative Keccak, 2048-digest workgroups
     {"P3HIP_KECCAK_COOP_MAX_LOG": "15", "P3HIP_KECCAK_COOP_CHUNK_LOG": "5"},
+    {"P3HIP_KECCAK_COOP_MAX_LOG": "12"},                                     # round 2's default
     {"P3HIP_NTT_NARROW_COSSPLIT": "0", "P3HIP_NTT_FUSED": "0", "P3HIP_HIDING_PIECEWISE": "1"},
     {"P3HIP_NTT_NARROW_F64": "0"},                                        # integer butterflies at every size
     {"P3HIP_NTT_NARROW_F64": "7", "P3HIP_VARIANT_BIG_LDE": "1"},          # fp64 butterflies at every size, incl. 12-stage digits

@@ -77,6 +77,20 @@ int main(int argc, char** argv) {
             if (proofs[0] != proof) { std::printf("FAIL batch proof 0 differs\n"); return 9; }
             std::printf("batch of %zu proofs (2^%u rows): %.1f ms, all verified\n", inst.size(), ln, ms);
         }
+        {   // the reference's two report strings from the library itself (lib.rs:37-131 -> fib_air::run_fib_air_zk / run_dft_benchmark)
+            std::string zk = run_fib_air_zk_report();  // its own instance and configuration: Keccak hashes, hiding MMCS + PCS, seed 1
+            std::printf("%s\n", zk.c_str());
+            if (zk != "fib_air zk ok (n=8, x=21)") { std::printf("FAIL run_fib_air_zk_report\n"); return 12; }
+            set_backend_kind_from_str("vulkan");
+            std::string refused = run_fib_air_zk_report();
+            set_backend_kind_from_str("hip");
+            if (refused.find("failed") == std::string::npos) { std::printf("FAIL the report ignored the selector\n"); return 13; }
+            std::string bm = run_dft_benchmark_report();  // no CPU column: libp3hip has no CPU transform to time
+            size_t lines = 1;
+            for (char ch : bm) lines += ch == '\n';
+            std::printf("%s\n", bm.substr(0, bm.find('\n')).c_str());
+            if (lines != 12 || bm.find("failed") != std::string::npos) { std::printf("FAIL run_dft_benchmark_report\n"); return 14; }
+        }
         std::printf("OK\n");
         return 0;
     } catch (const Error& e) {

@@ -65,3 +65,36 @@ def test_a_failing_rank_fails_the_launcher():
     # the stub refuses the RCCL backend: every rank raises, the parent must report a non-zero exit and print no line
     res = _bench(["--gpus", "2", "--steps", "1"], {"P3HIP_BENCH_STUB": "1", "P3HIP_BENCH_BACKEND": "gloo", "P3HIP_BENCH_STUB_FAIL": "1"})
     assert res.returncode != 0 and not [l for l in res.stdout.splitlines() if l.startswith("{")]
+
+
+def test_other_workloads_condenses_child_lines_and_survives_a_failing_child(monkeypatch):
+    """bench.py's default line carries short runs of the other configs (`other_workloads`), each this script in a child process.
+    The condensation and the failure handling are checked here with canned children: a child that fails leaves its error text and
+    the remaining ones still run."""
+    import importlib.util
+    import types
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    good = {"metric": "fib_air proofs/sec", "value": 19.1, "unit": "proofs/s", "steps": 2, "warmup": 1, "ms_per_step": 209.0,
+            "config": {"workload": "fib_air 2^24-row trace"},
+            "roofline": {"bound": "hbm", "achieved": 735.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.092, "traffic": 2.03e9, "avg_us": 912.0,
+                         "algorithmic_bytes": 671088640, "kernel": "coset_lde_batch", "commit": {"gperm_s": 7.5}},
+            "valu_roofline": {"hash": "Poseidon2-BabyBear-16", "achieved": 8.5, "frac": 0.97, "sustained_gperm_s": 7.7}}
+    calls = []
+
+    def fake_run(cmd, **kw):
+        calls.append(cmd)
+        if "cfg5" in cmd:
+            return types.SimpleNamespace(returncode=3, stdout="", stderr="boom: no HIP backend")
+        return types.SimpleNamespace(returncode=0, stdout="noise\n" + json.dumps(good) + "\n", stderr="")
+    monkeypatch.setattr("subprocess.run", fake_run)
+    res = bench.other_workloads()
+    assert len(res) == 4 and len(calls) == 4
+    assert all("--no-cpu-baseline" in c and "--no-extras" in c for c in calls)  # a child never recurses into extras
+    ok = [e for e in res if "error" not in e]
+    bad = [e for e in res if "error" in e]
+    assert len(ok) == 3 and len(bad) == 1 and "boom" in bad[0]["error"] and "cfg5" in bad[0]["command"]
+    e = ok[0]
+    assert e["value"] == 19.1 and e["roofline"]["frac"] == 0.092 and e["roofline"]["commit"] == {"gperm_s": 7.5}
+    assert e["valu_roofline"]["frac"] == 0.97 and e["workload"] == "fib_air 2^24-row trace"

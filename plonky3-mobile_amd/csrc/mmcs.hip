@@ -459,6 +459,50 @@ __global__ void __launch_bounds__(256) keccak_leaf_kernel(RowSet rs, uint64_t n_
     keccak_sponge_row(rs, r, st);
     store_digest64(digests + r * 8, st);
 }
+// WIDE rows under the Keccak sponge (as leaf_hash_f64_wide_kernel): the workgroup's 256 rows staged through LDS one rate block
+// (17 u64 = 34 words) at a time, loaded in row order (a wave reads ~2 rows' 136 contiguous bytes per instruction instead of 64 lines
+// 10 KB apart), read back by the row's lane as 16-byte pieces (row stride 36 words: conflict-free), the next block in flight
+// during the permutation of the current one.
+constexpr uint32_t KLEAF_WIDE_BLOCK = 34, KLEAF_WIDE_STRIDE = 36;
+__global__ void __launch_bounds__(256) keccak_leaf_wide_kernel(const uint32_t* mat, uint32_t width, uint64_t n_rows, uint32_t* digests) {
+    __shared__ __attribute__((aligned(16))) uint32_t tile[256 * KLEAF_WIDE_STRIDE];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t r0 = (uint64_t)blockIdx.x * 256u, r = r0 + tid;
+    uint64_t st[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) st[i] = 0;
+    uint32_t pre[KLEAF_WIDE_BLOCK];
+    auto fetch = [&](uint32_t c0) {
+#pragma unroll
+        for (uint32_t i = 0; i < KLEAF_WIDE_BLOCK; i++) {
+            const uint32_t e = tid + 256u * i, row = e / KLEAF_WIDE_BLOCK, col = e - row * KLEAF_WIDE_BLOCK;
+            pre[i] = (r0 + row < n_rows && c0 + col < width) ? mat[(r0 + row) * width + c0 + col] : 0u;
+        }
+    };
+    fetch(0);
+    for (uint32_t c0 = 0; c0 < width; c0 += KLEAF_WIDE_BLOCK) {
+        __syncthreads();  // the previous block has been read by every lane
+#pragma unroll
+        for (uint32_t i = 0; i < KLEAF_WIDE_BLOCK; i++) {
+            const uint32_t e = tid + 256u * i, row = e / KLEAF_WIDE_BLOCK, col = e - row * KLEAF_WIDE_BLOCK;
+            tile[row * KLEAF_WIDE_STRIDE + col] = pre[i];
+        }
+        __syncthreads();
+        const bool last = c0 + KLEAF_WIDE_BLOCK >= width;
+        if (!last) fetch(c0 + KLEAF_WIDE_BLOCK);  // in flight during the permutation below
+        const uint4* mine = reinterpret_cast<const uint4*>(tile + tid * KLEAF_WIDE_STRIDE);
+        uint32_t w[36];
+#pragma unroll
+        for (int k = 0; k < 9; k++) { const uint4 q = mine[k]; w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w; }
+#pragma unroll
+        for (int k = 0; k < 17; k++)
+            if (c0 + 2 * k < width) st[k] = (uint64_t)w[2 * k] | ((uint64_t)w[2 * k + 1] << 32);  // words past the row's end were staged as 0
+        if (last) kk::permute_digest(st);
+        else kk::permute(st);
+    }
+    if (r >= n_rows) return;
+    store_digest64(digests + r * 8, st);
+}
 // CompressionFunctionFromHasher<U64Hash, 2, 4>: hash of the 8 lanes of the two child digests (one block)
 __global__ void __launch_bounds__(256) keccak_compress_kernel(const uint32_t* prev, uint32_t* next, uint64_t n_out,
                                                               RowSet rs, uint32_t inject) {
@@ -691,7 +735,11 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
     if (kind == HASH_KECCAK) {
         // one state per lane for the large layers, the lane-cooperative form (shuffles inside a half-wave) for the small ones
         RowSet rs0 = make_rowset(*t, maxh);
-        hipLaunchKernelGGL(keccak_leaf_kernel, dim3((uint32_t)((maxh + 255) / 256)), dim3(256), 0, stream, rs0, maxh, t->layers);
+        if (rs0.count == 1 && rs0.width[0] >= 68 && leaf_wide_enabled())
+            hipLaunchKernelGGL(keccak_leaf_wide_kernel, dim3((uint32_t)((maxh + 255) / 256)), dim3(256), 0, stream, rs0.ptr[0], rs0.width[0], maxh,
+                               t->layers);
+        else
+            hipLaunchKernelGGL(keccak_leaf_kernel, dim3((uint32_t)((maxh + 255) / 256)), dim3(256), 0, stream, rs0, maxh, t->layers);
         P3_HIP(hipGetLastError());
         for (size_t l = 1; l < t->layer_len.size(); l++) {
             uint64_t len = t->layer_len[l];

@@ -81,18 +81,22 @@ def test_mmcs_headline_size(p3, oracle):
         assert oracle.mmcs_verify_batch(root, [(1 << 21, 2)], idx, rows[0], path)
 
 
-@pytest.mark.parametrize("h,w", [(4096, 64), (4096, 77), (8192, 333), (16384, 65), (4096, 2633)])
-def test_wide_rows_leaf_layer_vs_oracle(p3, oracle, h, w):
-    """Rows of >= 64 words take the LDS-staged leaf kernel (leaf_hash_f64_wide_kernel: 32-word chunks per row, partial last
-    chunk, widths that are not multiples of 8 or 32): every leaf digest and the root against the oracle's sponge."""
+@pytest.mark.parametrize("hash", ["poseidon2", "keccak"])
+@pytest.mark.parametrize("h,w", [(4096, 64), (4096, 77), (8192, 333), (16384, 65), (4096, 2633), (4096, 68), (4096, 102), (4096, 103)])
+def test_wide_rows_leaf_layer_vs_oracle(p3, oracle, h, w, hash):
+    """Wide rows take the LDS-staged leaf kernels (leaf_hash_f64_wide_kernel from 64 words: 32-word chunks per row;
+    keccak_leaf_wide_kernel from 68 words: one 34-word rate block per step; partial last chunks, odd widths, widths that are exact
+    multiples of the block): every leaf digest and the root against the oracle's sponge."""
     rng = np.random.default_rng(100 * w + h)
     m = _rand(rng, h, w)
-    root, tree = p3.MerkleTreeMmcs().commit([m])
+    kind = oracle.HASH_KECCAK if hash == "keccak" else oracle.HASH_POSEIDON2
+    root, tree = p3.MerkleTreeMmcs(hash).commit([m])
     leaves = tree.digest_layers()[0]
     rows = np.concatenate([np.arange(0, 300), rng.integers(0, h, 200), np.arange(h - 260, h)])
-    exp = np.stack([oracle.hash_row(m[r]) for r in rows])
+    hr = oracle.keccak_hash_row if hash == "keccak" else oracle.hash_row
+    exp = np.stack([hr(m[r]) for r in rows])
     assert np.array_equal(leaves[rows], exp)
-    oroot, _ = oracle.mmcs_commit([m])
+    oroot, _ = oracle.mmcs_commit([m], kind)
     assert np.array_equal(root, oroot)
     tree.free()
 

@@ -931,7 +931,9 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     // 32-byte row segments per tile: faster than the general plans up to W = 16 (1.3-2.1x), level from W = 32 on
     // W = 6 (the hiding prover's randomized trace, fib_air.rs:65: 2 columns + 4 random codewords): three column pairs per row
     static int wide_on = [] { const char* e = getenv("P3HIP_NTT_NARROW_WIDE"); return e ? atoi(e) : 1; }();
-    const bool wide = W > w_max && wide_on && n == 16 && W >= 64;  // 128-byte tile rows, single columns: any width
+    // 128-byte tile rows, single columns: any width whose byte offsets stay below 2^32 (the kernels index in u32: K1's
+    // transposed store reaches rows * W * 4 bytes of the coefficient matrix, K2 / K3 the LDE's (rows << added) * W * 4)
+    const bool wide = W > w_max && wide_on && n == 16 && W >= 64 && (((uint64_t)W << (n + added + 2)) < (1ull << 32));
     if (!wide && (W < 2 || W > w_max || !(is_pow2(W) || W == 6))) return 1;
     if (n < n_min || n < 16 || n > 24) return 1;
     if (!wide && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 7u)) return 1;  // 8-byte accesses
@@ -960,11 +962,21 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     static int use_blocked12 = [] { const char* e = getenv("P3HIP_NTT_NARROW_BLOCKED12"); return e ? atoi(e) : 1; }();
     const bool twelve = n1 >= 12 || n2 >= 12;
     a.blocked = use_blocked && !NARROW_MID_SEQ && W == 2 && !from_coeffs && (!twelve || use_blocked12);
-    const bool k3_out_of_place = a.blocked && (n1 >= 12 || k3_lq1);
+    bool k3_out_of_place = a.blocked && (n1 >= 12 || k3_lq1);
     uint32_t* mid = dst;  // K2's output = K3's input
     if (k3_out_of_place) {
-        if ((rc = cx.ws(stream, 3).reserve((N << added) * W * 4))) return rc;
-        mid = cx.ws(stream, 3).as<uint32_t>();
+        // slot 4 belongs to this function alone: slots 2 / 3 are the host-pointer entry points' staging buffers (c_api.hip
+        // dft_host), i.e. possible `src` / `dst` of this very call
+        const size_t mid_bytes = (N << added) * W * 4;
+        if ((rc = cx.ws(stream, 4).reserve(mid_bytes))) return rc;
+        mid = cx.ws(stream, 4).as<uint32_t>();
+        // K3 must never read the buffer its partner tiles write: if a caller's dst overlaps the scratch all the same, take
+        // the row-major intermediates (K3 in place, no half-owned blocks)
+        const uintptr_t m0 = reinterpret_cast<uintptr_t>(mid), d0 = reinterpret_cast<uintptr_t>(dst);
+        if (m0 < d0 + mid_bytes && d0 < m0 + mid_bytes) {
+            if (k3_lq1) return fail(ERR_INTERNAL, "lde_narrow: K3 scratch overlaps dst");
+            a.blocked = 0; k3_out_of_place = false; mid = dst;
+        }
     }
     a.from_coeffs = from_coeffs;
     a.mid_handover = use_handover;

@@ -25,6 +25,7 @@ VARIANTS = [
     {"P3HIP_NTT_NARROW_F64": "7", "P3HIP_NTT_NARROW_F64_XW": "1", "P3HIP_VARIANT_BIG_LDE": "1"},  # fp64 rounds, hand-overs on words
     {"P3HIP_RNG_TWO_PASS": "1", "P3HIP_LEAF_WIDE": "0", "P3HIP_HIDING_BARY_SPLIT": "1"},                    # first forms of the RNG fill and of the wide-row leaf kernel
     {"P3HIP_NTT_NARROW_BLOCKED12": "0", "P3HIP_NTT_NARROW_K3_LQ1": "1", "P3HIP_NTT_NARROW_WIDE": "0", "P3HIP_VARIANT_BIG_LDE": "1"},
+    {"P3HIP_NTT_NARROW_BLOCKED12": "0", "P3HIP_VARIANT_CFG3_LDE": "1"},   # cfg3's LDE shape on the row-major intermediates
 ]
 
 

@@ -26,6 +26,26 @@ def test_device_rng_stream_equals_host_stream(p3, oracle, seed):
     rng.close()
 
 
+def test_device_rng_far_jumps_equal_host_stream(p3, oracle):
+    """Fills as long as the ones the 2^20-row hiding prover issues (pcs stream ~1.0e8 draws, mmcs ~4e7, fri ~1.6e7; here
+    1.2e8, 5e7 and 1.7e7 back to back on ONE stream, so the second and third start from a state left by a far jump): every
+    GF(2) jump matrix T^(256*2^k) the bench uses (k up to 19) is on the path, every element and the state afterwards are
+    compared with the sequential host loop."""
+    import torch
+    rng = p3.DeviceRng(1)
+    host = oracle.rng_seed_from_u64(1)
+    for n in [120_000_000, 50_000_000, 17_000_001]:
+        got = rng.fill_field(n)
+        torch.cuda.synchronize()
+        exp = oracle.rng_fill_field(host, n)
+        got_h = p3.host_u32(got)
+        del got
+        assert np.array_equal(got_h, exp), n
+        assert rng.state() == list(host), n
+        del got_h, exp
+    rng.close()
+
+
 def _fp(p3, oracle, *t):
     return p3.FriParameters(*t), oracle.FriParams(*t)
 
@@ -122,6 +142,25 @@ def test_hiding_bench_size_in_the_reference_configuration(p3, oracle):
     assert oracle.verify_fib_air_hiding(proof, 0, 1, (x + 1) % 0x78000001, 20, ofp, hash=oracle.HASH_KECCAK) != 0
     assert pr.prove(0, 1) == proof
     pr.close()
+
+
+def test_hiding_bench_size_proof_bytes_equal_oracle_slow(p3, oracle):
+    """The bench's own instance (2^20-row trace, Keccak hashes, hiding, seed 1, benchmark FRI parameters) BYTE FOR BYTE against
+    the oracle prover on all host cores (accept / reject alone is blind to the random values: the far jumps of the three
+    streams, the salts of 2^22-row trees and the blinding all enter these bytes).  About a minute of CPU."""
+    gfp, ofp = _fp(p3, oracle, 1, 0, 100, 16)
+    pr = p3.FibAirProver(20, params=gfp, hash="keccak", hiding=True, seed=1)
+    proof = pr.prove(0, 1)
+    pr.close()
+    oracle.set_threads(oracle.max_threads())
+    try:
+        ref = oracle.prove_fib_air_hiding(0, 1, 20, ofp, hash=oracle.HASH_KECCAK, seed=1)
+    finally:
+        oracle.set_threads(1)
+    assert len(proof) == len(ref)
+    if proof != ref:
+        w1, w2 = np.frombuffer(proof, np.uint32), np.frombuffer(ref, np.uint32)
+        pytest.fail("proof words differ first at %d of %d" % (int(np.nonzero(w1 != w2)[0][0]), len(w1)))
 
 
 @pytest.mark.parametrize("log_n", [14, 15, 16, 17])

@@ -216,13 +216,36 @@ def test_randomized_large_shapes(dft, oracle, p3):
 def test_narrow_three_launch_lde(dft, oracle, p3, log_h, w, ab):
     """The two-digit, three-launch LDE for narrow matrices (ntt_narrow.hip.h; W in {2, 4, 8, 16}, 2^16..2^24 rows,
     bit-reversed output): every digit size 8..11 in both positions, every slot/row split, blowup 2, 4 and 8,
-    against the oracle bit for bit.  (2^24 is covered by the cfg3 round-trip/proof tests.)"""
+    against the oracle bit for bit.  (2^24 x 2 at blowup 4 — BASELINE configs[2]'s own shape — is the next test.)"""
     rng = np.random.default_rng(1000 * log_h + 10 * w + ab)
     x = _rand(rng, 1 << log_h, w)
     shift = p3.GENERATOR_MONTY if (log_h + w) % 2 == 0 else int(rng.integers(1, P))
     exp = oracle.coset_lde_batch(x, ab, shift, True)
     got = dft.coset_lde_batch(x, ab, shift, bit_reversed_out=True)
     assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("log_h,ab", [(23, 1), (24, 2)])
+def test_twelve_stage_digit_lde_host_and_device_paths(dft, oracle, p3, log_h, ab):
+    """12-stage digits (2^23 / 2^24 rows x 2): blocked intermediates, K3 out of place with partner tiles.  (24, 2) with shift
+    GENERATOR is cfg3's trace LDE itself (2^24 x 2 -> 2^26 x 2), compared element by element.  Both entry points: the
+    host-pointer one stages `dst` in a context scratch buffer (c_api.hip dft_host) — K3's own scratch must not be that buffer
+    (round-3 advisor finding: slot 3 was shared, K3 read what its partner tiles overwrote) — and the `_dev` one with a
+    caller-owned output.  Each path twice, so the second call runs with every scratch buffer already at its final size."""
+    import torch
+    rng = np.random.default_rng(120000 + log_h)
+    x = _rand(rng, 1 << log_h, 2)
+    exp = oracle.coset_lde_batch(x, ab, p3.GENERATOR_MONTY, True)
+    for rep in range(2):
+        got = dft.coset_lde_batch(x, ab, p3.GENERATOR_MONTY, bit_reversed_out=True)
+        assert np.array_equal(got, exp), ("host path", rep)
+        del got
+    dx = p3.dev_u32(x)
+    for rep in range(2):
+        dgot = dft.coset_lde_batch(dx, ab, p3.GENERATOR_MONTY, bit_reversed_out=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(p3.host_u32(dgot), exp), ("device path", rep)
+        del dgot
 
 
 @pytest.mark.parametrize("log_h,ab", [(16, 1), (17, 2), (18, 1), (19, 3), (20, 1), (21, 1), (22, 1)])

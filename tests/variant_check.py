@@ -38,6 +38,8 @@ dft = p3.GpuDft.with_backend(p3.BackendKind.Hip)
 shapes = [(16, 2, 1), (17, 4, 2), (18, 8, 1), (19, 2, 3), (20, 2, 1), (21, 2, 1), (22, 4, 1), (16, 6, 1), (16, 77, 1)]
 if os.environ.get("P3HIP_VARIANT_BIG_LDE") == "1":
     shapes.append((23, 2, 1))  # 12-stage digits
+if os.environ.get("P3HIP_VARIANT_CFG3_LDE") == "1":
+    shapes.append((24, 2, 2))  # BASELINE configs[2]'s trace LDE, element-wise, under this variant's switches
 for log_h, w, ab in shapes:
     x = rng.integers(0, P, (1 << log_h, w), dtype=np.uint32)
     got = p3.host_u32(dft.coset_lde_batch(p3.dev_u32(x), ab, p3.GENERATOR_MONTY, bit_reversed_out=True))

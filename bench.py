@@ -123,6 +123,9 @@ def cpu_baseline_wide(job):
             "seconds_estimated_whole_job": est, "lde_columns_equal_to_gpu": same, "leaf_digests_equal_to_gpu": same_d}
 
 
+HOST_CORES, PINNING = [], "not evaluated"
+
+
 def other_workloads():
     """The default run (what the driver records) also carries SHORT runs of the other single-GPU BASELINE configs and of the
     reference's own configuration, so that their numbers are in a driver-run record and not only in builder-run profiles:
@@ -160,6 +163,45 @@ def other_workloads():
         entry["wall_s"] = round(time.perf_counter() - t0, 1)
         res.append(entry)
     return res
+
+
+def parse_cpulist(text):
+    """'0-15,64-79' -> {0..15, 64..79} (the kernel's cpulist format)."""
+    cores = set()
+    for part in text.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cores.update(range(int(lo), int(hi or lo) + 1))
+    return cores
+
+
+def pin_to_gpu_local_cores(torch, device_index, world, sysfs="/sys/bus/pci/devices"):
+    """Multi-rank runs: restrict this rank (and every thread it starts afterwards) to the host cores local to its GPU, read from
+    /sys/bus/pci/devices/<bdf>/local_cpulist, intersected with the affinity mask the launcher gave us.  Anything unreadable or an
+    empty intersection: nothing is changed.  Returns (cores in the mask afterwards, description for the JSON line)."""
+    have = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
+    if world <= 1 and os.environ.get("P3HIP_BENCH_PIN") != "1":
+        return have, "none (single rank: the launcher's mask is kept)"
+    if os.environ.get("P3HIP_BENCH_PIN") == "0":
+        return have, "none (P3HIP_BENCH_PIN=0)"
+    try:
+        if os.environ.get("P3HIP_BENCH_PIN_CPULIST"):  # tests: stands in for the sysfs file
+            local, src = parse_cpulist(os.environ["P3HIP_BENCH_PIN_CPULIST"]), "P3HIP_BENCH_PIN_CPULIST"
+        else:
+            pr = torch.cuda.get_device_properties(device_index)
+            bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            src = os.path.join(sysfs, bdf, "local_cpulist")
+            with open(src) as f:
+                local = parse_cpulist(f.read())
+        want = sorted(local & set(have))
+        if not want:
+            return have, "none (%s has no core inside this process's mask)" % src
+        os.sched_setaffinity(0, want)
+        return want, "pinned to the %d core(s) of %s inside the launcher's mask" % (len(want), src)
+    except Exception as e:  # noqa: BLE001 - unreadable sysfs, no such attribute, not permitted: leave the mask alone
+        return have, "none (%s: %s)" % (type(e).__name__, e)
 
 
 def launch_ranks(n, argv):
@@ -266,6 +308,9 @@ def main():
     n_dev = torch.cuda.device_count()
     if not stub:
         torch.cuda.set_device(local_rank % max(n_dev, 1))
+    # before any worker thread exists: threads inherit the mask
+    global HOST_CORES, PINNING
+    HOST_CORES, PINNING = pin_to_gpu_local_cores(torch, local_rank % max(n_dev, 1), world)
     # backend "nccl" IS RCCL on ROCm.  P3HIP_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with
     # fewer GPUs than ranks (collectives then move host tensors).
     backend = os.environ.get("P3HIP_BENCH_BACKEND", "nccl")
@@ -384,9 +429,21 @@ def run(args, job, dist, world, rank, local_rank, n_dev, backend, coll_dev, use_
     if sharded and os.environ.get("P3HIP_BENCH_NO_GATHER"):
         coll_state["mode"] = "disabled by P3HIP_BENCH_NO_GATHER: local sharding only"
 
+    # where a rank's wall time goes besides proving (seconds, timed region only): blocked in the scatter of the next step's
+    # descriptors, blocked in retire() on the previous step's gather, blocked waiting for its own provers to finish a step
+    waits = {"scatter_wait_s": 0.0, "gather_wait_s": 0.0, "prover_join_s": 0.0}
+    timing = {"on": False}
+
+    def timed(key, fn):
+        t_in = time.perf_counter()
+        r = fn()
+        if timing["on"]:
+            waits[key] += time.perf_counter() - t_in
+        return r
+
     def descriptors(k):
         inst = [(k * n_total + i, k * n_total + i + 1) for i in range(n_total)] if rank == 0 else []
-        return pbatch.scatter_descriptors(inst, device=coll_dev)
+        return timed("scatter_wait_s", lambda: pbatch.scatter_descriptors(inst, device=coll_dev))
 
     # Steps are PIPELINED (depth 1): step k + 1 is issued — its instances dealt to the prover threads' queue — before
     # step k retires, so a prover that has finished its share of step k starts on step k + 1 at once instead of
@@ -428,11 +485,14 @@ def run(args, job, dist, world, rank, local_rank, n_dev, backend, coll_dev, use_
         return slot
 
     def retire(slot):
-        got = job.step_end()
+        got = timed("prover_join_s", job.step_end)
         if slot is None:
             return got
-        prev, coll_state["pending"] = coll_state.get("pending"), coll_state["gatherer"].launch(slot)
-        return prev.wait(copy=False) if prev is not None else None
+
+        def gather():
+            prev, coll_state["pending"] = coll_state.get("pending"), coll_state["gatherer"].launch(slot)
+            return prev.wait(copy=False) if prev is not None else None
+        return timed("gather_wait_s", gather)
 
     def run_steps(first, count):
         # A failed collective is FATAL: an N-GPU line must never be printed without RCCL having moved the batch.
@@ -446,7 +506,7 @@ def run(args, job, dist, world, rank, local_rank, n_dev, backend, coll_dev, use_
             retire(inflight.pop(0))
             pend = coll_state.pop("pending", None)
             if pend is not None:
-                pend.wait(copy=False)  # the last step's proofs must be on rank 0 inside the timed region
+                timed("gather_wait_s", lambda: pend.wait(copy=False))  # the last step's proofs must be on rank 0 inside the timed region
         except Exception as e:
             if not use_gather:
                 raise
@@ -456,20 +516,37 @@ def run(args, job, dist, world, rank, local_rank, n_dev, backend, coll_dev, use_
 
     run_steps(0, args.warmup)
     barrier()
+    timing["on"] = True
     t0 = time.perf_counter()
     run_steps(args.warmup, args.steps)
+    own_wall = time.perf_counter() - t0  # this rank's own steps, before it waits for the slowest rank
     barrier()
     elapsed = time.perf_counter() - t0
+    timing["on"] = False
     cur_dev = -1 if stub else torch.cuda.current_device()
-    ranks_info = [{"rank": rank, "local_rank": local_rank, "device_count": n_dev, "device": cur_dev}]
+    # one row per rank, so that an N-rank line explains itself: what the rank proved, how long its own steps took, where it waited
+    # (a scaling loss shows up as one rank's prove_wall_s, or as gather / scatter waits), and which host cores it ran on
+    int_keys = ("rank", "local_rank", "device_count", "device", "proofs", "host_cores", "pinned")
+    flt_keys = ("prove_wall_s", "scatter_wait_s", "gather_wait_s", "prover_join_s")
+    mine = [rank, local_rank, n_dev, cur_dev, args.batch * args.steps, len(HOST_CORES), 1 if PINNING.startswith("pinned") else 0,
+            own_wall, waits["scatter_wait_s"], waits["gather_wait_s"], waits["prover_join_s"]]
+
+    def rank_row(vals):
+        d = {k: int(v) for k, v in zip(int_keys, vals)}
+        d.update({k: round(float(v), 4) for k, v in zip(flt_keys, vals[len(int_keys):])})
+        d["proofs_per_s"] = round(d["proofs"] / d["prove_wall_s"], 2) if d["prove_wall_s"] > 0 else None
+        return d
+    ranks_info = [rank_row(mine)]
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        info = torch.tensor([rank, local_rank, n_dev, cur_dev], dtype=torch.int64, device=coll_dev)
+        info = torch.tensor(mine, dtype=torch.float64, device=coll_dev)
         infos = [torch.empty_like(info) for _ in range(world)]
         dist.all_gather(infos, info)
-        ranks_info = [dict(zip(("rank", "local_rank", "device_count", "device"), [int(v) for v in i.cpu().tolist()])) for i in infos]
+        ranks_info = [rank_row(i.cpu().tolist()) for i in infos]
+    ranks_info[rank if use_dist else 0]["host_core_list"] = ",".join(map(str, HOST_CORES[:64])) + ("..." if len(HOST_CORES) > 64 else "")
+    ranks_info[rank if use_dist else 0]["pinning"] = PINNING
     units = args.batch * args.steps * world
     value = units / elapsed
 
@@ -499,6 +576,10 @@ def run(args, job, dist, world, rank, local_rank, n_dev, backend, coll_dev, use_
         "world_size": world,
         "dist_backend": (backend + (" (= RCCL on ROCm)" if backend == "nccl" else "")) if use_dist else None,
         "ranks": ranks_info,
+        "ranks_note": "per rank: proofs and prove_wall_s of its own timed steps (before the closing barrier), seconds blocked in the "
+                      "descriptor scatter / in retire() on the proof gather / joining its own provers, host cores in its affinity mask; "
+                      "host_core_list and pinning are rank 0's (every rank applies the same rule to its own GPU)",
+        "gather_bytes_per_step": (n_total * coll_state["width"]) if use_gather and "width" in coll_state else 0,
         "parity": "proof bytes / digests are compared with the repo's C oracle (a restatement of upstream Plonky3 from "
                   "recall; pinned by reference code only for the DFT): self-consistent, upstream parity UNPINNED",
     }

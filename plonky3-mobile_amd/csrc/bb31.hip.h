@@ -47,18 +47,43 @@ BB_HD uint32_t monty_reduce(uint64_t x) {
     uint32_t r = hi - u;
     return umin32(r, r + P);
 }
-// Montgomery product.  lo/hi are taken with separate v_mul_lo_u32 / v_mul_hi_u32: hipcc otherwise fuses the
-// 64-bit product into v_mad_u64_u32, which issues ~3x slower than the pair on gfx950
-// (profiles/r01_microbench2_valu_issue_rates.txt).
+// Montgomery product, FIVE instructions on gfx950: v_mad_u64_u32 (x = a b), v_mul_lo_u32 (t = lo(x) * -P^-1), v_mad_u64_u32
+// (x + t P: the low word cancels, the high word is the result in [0, 2P)), v_add, v_min.  Until round 3 this was the seven-
+// instruction form (v_mul_lo, v_mul_hi, v_mul_lo, v_mul_hi, v_sub, v_add, v_min) on the strength of round 1's first issue-rate
+// probe, which had v_mad_u64_u32 at a third of the multiplies' rate; the second probe (profiles/r01_microbench2_valu_issue_rates.txt:
+// 557 against 566 G wave-instructions/s at eight waves per SIMD) and a butterfly loop timed both ways
+// (tools/mulform_bench.hip, profiles/r04_mulform_bench.txt: +9 % butterflies/s) say otherwise.  Same value for every input.
+// BB_MUL_SPLIT=1 (compile time) restores the seven-instruction form.
+#ifndef BB_MUL_SPLIT
+#define BB_MUL_SPLIT 0
+#endif
+constexpr uint32_t NMU = 0u - MU;  // -P^-1 mod 2^32
 BB_HD uint32_t mul(uint32_t a, uint32_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && BB_MUL_SPLIT
     uint32_t lo = a * b, hi = __umulhi(a, b);
     uint32_t t = lo * MU;
     uint32_t u = __umulhi(t, P);
     uint32_t r = hi - u;
     return umin32(r, r + P);
+#elif defined(__HIP_DEVICE_COMPILE__)
+    const uint64_t x = (uint64_t)a * b;
+    const uint32_t t = (uint32_t)x * NMU;
+    const uint32_t r = (uint32_t)((x + (uint64_t)t * P) >> 32);  // x + t P < P^2 + 2^32 P < 2^64
+    return umin32(r, r - P);
 #else
     return monty_reduce((uint64_t)a * b);
+#endif
+}
+// sum of two products under ONE reduction: a0 b0 + a1 b1 < 2 P^2 < 2^32 P, so the 64-bit sum is a valid Montgomery input
+// (two v_mad_u64_u32 + the three-instruction tail instead of two products and a modular addition: 6 instead of 13)
+BB_HD uint32_t dot2(uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1) {
+#if defined(__HIP_DEVICE_COMPILE__) && !BB_MUL_SPLIT
+    const uint64_t x = (uint64_t)a0 * b0 + (uint64_t)a1 * b1;
+    const uint32_t t = (uint32_t)x * NMU;
+    const uint32_t r = (uint32_t)((x + (uint64_t)t * P) >> 32);  // < (2 P^2 + 2^32 P) / 2^32 < 2P
+    return umin32(r, r - P);
+#else
+    return monty_reduce((uint64_t)a0 * b0 + (uint64_t)a1 * b1);
 #endif
 }
 BB_HD uint32_t sqr(uint32_t a) { return mul(a, a); }
@@ -135,20 +160,16 @@ BB_HD Ext scale(const Ext& a, uint32_t s) {
 BB_HD bool eq(const Ext& a, const Ext& b) {
     return a.c[0] == b.c[0] && a.c[1] == b.c[1] && a.c[2] == b.c[2] && a.c[3] == b.c[3];
 }
-// Schoolbook product with delayed reduction: each output coefficient is a sum of at most 4 products
-// (three of them scaled by 11 afterwards), accumulated as 64-bit values below 2^32*P before ONE
-// Montgomery reduction.  a_i*b_j < P^2 < 2^62; we reduce the high part first to stay in range.
+// Schoolbook product modulo x^4 - 11: every output coefficient is a sum of four products (b pre-multiplied by 11 where the
+// index wraps), taken two products per Montgomery reduction (dot2): 4 x (two dot2 + one addition) + three products by 11 =
+// 75 instructions instead of the 16 products, 3 products by 11 and 12 additions (169) of the first form.  Exact field
+// arithmetic: the value does not depend on the grouping.
 BB_HD Ext mul(const Ext& a, const Ext& b) {
-    // t_k = sum_{i+j=k} a_i b_j  (k = 0..6), reduced individually to [0,P) via monty (keeps it simple
-    // and exact); then c_k = t_k + 11 t_{k+4}.
-    uint32_t t0 = mul(a.c[0], b.c[0]);
-    uint32_t t1 = add(mul(a.c[0], b.c[1]), mul(a.c[1], b.c[0]));
-    uint32_t t2 = add(add(mul(a.c[0], b.c[2]), mul(a.c[1], b.c[1])), mul(a.c[2], b.c[0]));
-    uint32_t t3 = add(add(mul(a.c[0], b.c[3]), mul(a.c[1], b.c[2])), add(mul(a.c[2], b.c[1]), mul(a.c[3], b.c[0])));
-    uint32_t t4 = add(add(mul(a.c[1], b.c[3]), mul(a.c[2], b.c[2])), mul(a.c[3], b.c[1]));
-    uint32_t t5 = add(mul(a.c[2], b.c[3]), mul(a.c[3], b.c[2]));
-    uint32_t t6 = mul(a.c[3], b.c[3]);
-    return Ext{{add(t0, mul(t4, W_MONTY)), add(t1, mul(t5, W_MONTY)), add(t2, mul(t6, W_MONTY)), t3}};
+    const uint32_t w1 = mul(b.c[1], W_MONTY), w2 = mul(b.c[2], W_MONTY), w3 = mul(b.c[3], W_MONTY);
+    return Ext{{add(dot2(a.c[0], b.c[0], a.c[1], w3), dot2(a.c[2], w2, a.c[3], w1)),
+                add(dot2(a.c[0], b.c[1], a.c[1], b.c[0]), dot2(a.c[2], w3, a.c[3], w2)),
+                add(dot2(a.c[0], b.c[2], a.c[1], b.c[1]), dot2(a.c[2], b.c[0], a.c[3], w3)),
+                add(dot2(a.c[0], b.c[3], a.c[1], b.c[2]), dot2(a.c[2], b.c[1], a.c[3], b.c[0]))}};
 }
 BB_HD Ext sqr(const Ext& a) { return mul(a, a); }
 BB_HD Ext pow(Ext base, uint64_t e) {

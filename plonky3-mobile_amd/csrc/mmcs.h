@@ -11,7 +11,7 @@ enum HashKind : int { HASH_POSEIDON2 = 0, HASH_KECCAK = 1 };
 struct Tree {
     int kind = HASH_POSEIDON2;
     std::vector<const uint32_t*> mats;  // borrowed device pointers (or entries of `owned`)
-    std::vector<size_t> heights, widths;
+    std::vector<size_t> heights, widths, strides;  // strides: words between rows (= widths for dense matrices)
     std::vector<void*> owned;           // device copies made by the host-pointer commit
     uint32_t* layers = nullptr;         // all digest layers, leaf layer first, 8 words per digest
     bool root_copied = false;           // the top kernel also wrote the root to the caller's host-mapped buffer
@@ -24,9 +24,10 @@ struct Tree {
 };
 
 // ext_layers: optional caller-owned storage of (2*max_height - 1) * 8 words for the digest layers.
+// strides: optional words between two rows per matrix (a matrix may be a column group of a wider one); default = widths.
 int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t* heights, const size_t* widths,
                 size_t n_mats, Tree** out, uint32_t* ext_layers = nullptr, uint32_t* root_copy = nullptr,
-                int kind = HASH_POSEIDON2);
+                int kind = HASH_POSEIDON2, const size_t* strides = nullptr);
 inline size_t mmcs_layer_words(uint64_t max_height) { return (size_t)(2 * max_height - 1) * 8; }
 int mmcs_root(hipStream_t stream, const Tree& t, uint32_t root_out[8]);
 int mmcs_open(hipStream_t stream, const Tree& t, uint64_t index, uint32_t* rows_out, uint32_t* path_out);

@@ -23,6 +23,7 @@ constexpr int MAX_CLASS_MATS = 16;
 struct RowSet {  // the matrices of one height class, concatenated row-wise
     const uint32_t* ptr[MAX_CLASS_MATS];
     uint32_t width[MAX_CLASS_MATS];
+    uint32_t stride[MAX_CLASS_MATS];  // words between two rows (= width unless the matrix is a column group of a wider one)
     uint32_t count;
     uint32_t total;
 };
@@ -44,7 +45,7 @@ __device__ __forceinline__ void sponge_row(const RowSet& rs, uint64_t r, uint32_
 #pragma unroll
     for (int i = 0; i < 16; i++) s[i] = 0;
     if (rs.count == 1) {
-        const uint32_t* row = rs.ptr[0] + r * rs.width[0];
+        const uint32_t* row = rs.ptr[0] + r * rs.stride[0];
         const uint32_t w = rs.width[0];
         for (uint32_t k = 0; k < w; k += 8) {
 #pragma unroll
@@ -60,7 +61,7 @@ __device__ __forceinline__ void sponge_row(const RowSet& rs, uint64_t r, uint32_
         for (int i = 0; i < 8; i++) {
             if (k + i < rs.total) {
                 while (off >= rs.width[m]) { m++; off = 0; }
-                s[i] = rs.ptr[m][r * rs.width[m] + off];
+                s[i] = rs.ptr[m][r * rs.stride[m] + off];
                 off++;
             }
         }
@@ -219,7 +220,7 @@ __global__ void __launch_bounds__(256) leaf_hash_f64_rowset_kernel(RowSet rs, ui
         for (int i = 0; i < 8; i++) {
             if (k + i < rs.total) {
                 while (off >= rs.width[m]) { m++; off = 0; }
-                s[i] = p2f::load_elem(rs.ptr[m][r * rs.width[m] + off]);
+                s[i] = p2f::load_elem(rs.ptr[m][r * rs.stride[m] + off]);
                 off++;
             }
         }
@@ -425,7 +426,7 @@ int poseidon2_permute_states(hipStream_t stream, uint32_t* d_states, uint64_t n)
 __device__ __forceinline__ uint32_t rowset_elem(const RowSet& rs, uint64_t r, uint32_t k, uint32_t& m, uint32_t& base) {
     // element k of the concatenated row (k only ever increases between calls: m/base are the running cursor)
     while (k - base >= rs.width[m]) { base += rs.width[m]; m++; }
-    return rs.ptr[m][r * rs.width[m] + (k - base)];
+    return rs.ptr[m][r * rs.stride[m] + (k - base)];
 }
 __device__ __forceinline__ void keccak_sponge_row(const RowSet& rs, uint64_t r, uint64_t (&st)[25]) {
 #pragma unroll
@@ -459,6 +460,89 @@ __global__ void __launch_bounds__(256) keccak_leaf_kernel(RowSet rs, uint64_t n_
     keccak_sponge_row(rs, r, st);
     store_digest64(digests + r * 8, st);
 }
+// SALTED leaves of the hiding MMCS (MerkleTreeHidingMmcs, fib_air.rs:40-51): the tallest class is NP (matrix, salt) pairs, leaf row =
+// m0 || s0 || m1 || s1 ..., every matrix W in {4, 6, 8} words wide, every salt 4, at most one rate block (34 words) in all — the
+// hiding prover's trace (6 + 4), randomization (8 + 4), FRI layer (8 + 4) and four-chunk quotient (4 x (4 + 4)) commitments.  The
+// generic kernel walks the row set one word at a time through a running (matrix, column) cursor; here every row piece is one
+// 8- or 16-byte load at a compile-time position of the state.  `stride` = words between two rows of a matrix (the four chunk
+// matrices are the column groups of ONE 16-word-wide LDE).
+template <int NP>
+struct SaltedRows {
+    const uint32_t* mat[NP];
+    const uint32_t* salt[NP];
+    uint32_t stride;
+};
+template <int W, int NP>
+__global__ void __launch_bounds__(256) keccak_leaf_salted_kernel(SaltedRows<NP> a, uint64_t n_rows, uint32_t* digests) {
+    static_assert((W == 4 || W == 6 || W == 8) && NP * (W + 4) <= 34, "one rate block");
+    if (gridDim.x <= 512u) P3_LATENCY_BOUND_KERNEL();
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    uint64_t st[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) st[i] = 0;
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        constexpr int L = (W + 4) / 2;  // lanes per pair
+        const uint32_t* m = a.mat[p] + r * a.stride;
+        if constexpr (W == 6) {
+            const uint2* q = reinterpret_cast<const uint2*>(m);
+#pragma unroll
+            for (int k = 0; k < 3; k++) { const uint2 v = q[k]; st[p * L + k] = (uint64_t)v.x | ((uint64_t)v.y << 32); }
+        } else {
+            const uint4* q = reinterpret_cast<const uint4*>(m);
+#pragma unroll
+            for (int k = 0; k < W / 4; k++) {
+                const uint4 v = q[k];
+                st[p * L + 2 * k] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+                st[p * L + 2 * k + 1] = (uint64_t)v.z | ((uint64_t)v.w << 32);
+            }
+        }
+        const uint4 sv = *reinterpret_cast<const uint4*>(a.salt[p] + r * 4);
+        st[p * L + W / 2] = (uint64_t)sv.x | ((uint64_t)sv.y << 32);
+        st[p * L + W / 2 + 1] = (uint64_t)sv.z | ((uint64_t)sv.w << 32);
+    }
+    kk::permute_digest(st);
+    store_digest64(digests + r * 8, st);
+}
+// (matrix, salt) x NP with equal matrix widths and 16-byte-aligned rows?  Fills `a` and returns the width, else 0.
+template <int NP>
+static uint32_t salted_rows_of(const RowSet& rs, SaltedRows<NP>* a) {
+    if (rs.count != 2u * NP) return 0;
+    const uint32_t w = rs.width[0];
+    if (w != 4 && w != 6 && w != 8) return 0;
+    for (int p = 0; p < NP; p++) {
+        if (rs.width[2 * p] != w || rs.width[2 * p + 1] != 4 || rs.stride[2 * p] != rs.stride[0] || rs.stride[2 * p + 1] != 4) return 0;
+        if (rs.stride[0] & (w == 6 ? 1u : 3u)) return 0;
+        if ((reinterpret_cast<uintptr_t>(rs.ptr[2 * p]) & (w == 6 ? 7u : 15u)) || (reinterpret_cast<uintptr_t>(rs.ptr[2 * p + 1]) & 15u)) return 0;
+        a->mat[p] = rs.ptr[2 * p]; a->salt[p] = rs.ptr[2 * p + 1];
+    }
+    a->stride = rs.stride[0];
+    return w;
+}
+static bool leaf_salted_enabled() {  // P3HIP_LEAF_SALTED=0: the generic row-set kernel for the hiding MMCS's leaves too
+    static const bool on = [] { const char* e = getenv("P3HIP_LEAF_SALTED"); return !e || atoi(e) != 0; }();
+    return on;
+}
+// returns true when a salted-leaf kernel was launched for the tallest class
+static bool launch_keccak_leaf_salted(hipStream_t stream, const RowSet& rs, uint64_t n_rows, uint32_t* digests) {
+    if (!leaf_salted_enabled()) return false;
+    const dim3 grid((uint32_t)((n_rows + 255) / 256)), block(256);
+    SaltedRows<1> a1;
+    SaltedRows<4> a4;
+    if (const uint32_t w = salted_rows_of<1>(rs, &a1)) {
+        if (w == 4) hipLaunchKernelGGL((keccak_leaf_salted_kernel<4, 1>), grid, block, 0, stream, a1, n_rows, digests);
+        else if (w == 6) hipLaunchKernelGGL((keccak_leaf_salted_kernel<6, 1>), grid, block, 0, stream, a1, n_rows, digests);
+        else hipLaunchKernelGGL((keccak_leaf_salted_kernel<8, 1>), grid, block, 0, stream, a1, n_rows, digests);
+        return true;
+    }
+    if (salted_rows_of<4>(rs, &a4) == 4) {
+        hipLaunchKernelGGL((keccak_leaf_salted_kernel<4, 4>), grid, block, 0, stream, a4, n_rows, digests);
+        return true;
+    }
+    return false;
+}
+
 // WIDE rows under the Keccak sponge (as leaf_hash_f64_wide_kernel): the workgroup's 256 rows staged through LDS one rate block
 // (17 u64 = 34 words) at a time, loaded in row order (a wave reads ~2 rows' 136 contiguous bytes per instruction instead of 64 lines
 // 10 KB apart), read back by the row's lane as 16-byte pieces (row stride 36 words: conflict-free), the next block in flight
@@ -622,6 +706,7 @@ int keccak_f_states(hipStream_t stream, uint64_t* d_states, uint64_t n) {
 struct OpenArgs {
     const uint32_t* mat[64];
     uint32_t width[64];
+    uint32_t stride[64];
     uint32_t shift[64];  // log_max_height - log_height
     uint32_t n_mats;
     uint32_t log_max_height;
@@ -632,7 +717,7 @@ __global__ void open_gather_kernel(OpenArgs a, const uint32_t* layers, uint64_t 
     uint32_t off = 0;
     for (uint32_t m = 0; m < a.n_mats; m++) {
         uint64_t r = index >> a.shift[m];
-        for (uint32_t c = threadIdx.x; c < a.width[m]; c += blockDim.x) out[off + c] = a.mat[m][r * a.width[m] + c];
+        for (uint32_t c = threadIdx.x; c < a.width[m]; c += blockDim.x) out[off + c] = a.mat[m][r * a.stride[m] + c];
         off += a.width[m];
     }
     // siblings: layer i starts at sum_{j<i} (maxh >> j) * 8 words
@@ -651,6 +736,7 @@ static RowSet make_rowset(const Tree& t, uint64_t h) {
         if (t.heights[m] == h) {
             rs.ptr[rs.count] = t.mats[m];
             rs.width[rs.count] = (uint32_t)t.widths[m];
+            rs.stride[rs.count] = (uint32_t)t.strides[m];
             rs.total += (uint32_t)t.widths[m];
             rs.count++;
         }
@@ -679,7 +765,7 @@ Tree::~Tree() {
 }
 
 int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t* heights, const size_t* widths,
-                size_t n_mats, Tree** out, uint32_t* ext_layers, uint32_t* root_copy, int kind) {
+                size_t n_mats, Tree** out, uint32_t* ext_layers, uint32_t* root_copy, int kind, const size_t* strides) {
     if (kind != HASH_POSEIDON2 && kind != HASH_KECCAK) return fail(ERR_BAD_ARG, "mmcs_commit: unknown hash configuration");
     if (!n_mats || !d_mats || !heights || !widths || !out) return fail(ERR_BAD_ARG, "mmcs_commit: null/empty argument");
     if (n_mats > 64) return fail(ERR_BAD_ARG, "mmcs_commit: at most 64 matrices per commitment");
@@ -691,7 +777,12 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
     }
     std::unique_ptr<Tree> t(new Tree());
     t->kind = kind;
-    for (size_t i = 0; i < n_mats; i++) { t->mats.push_back(d_mats[i]); t->heights.push_back(heights[i]); t->widths.push_back(widths[i]); }
+    for (size_t i = 0; i < n_mats; i++) {
+        t->mats.push_back(d_mats[i]); t->heights.push_back(heights[i]); t->widths.push_back(widths[i]);
+        const size_t st = strides ? strides[i] : widths[i];
+        if (st < widths[i] || st > 0xffffffffull) return fail(ERR_BAD_ARG, "mmcs_commit: row stride below the width");
+        t->strides.push_back(st);
+    }
     t->log_max_height = log2u(maxh);
     for (uint64_t h = maxh; h >= 1; h >>= 1) {
         size_t cnt = 0;
@@ -735,10 +826,10 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
     if (kind == HASH_KECCAK) {
         // one state per lane for the large layers, the lane-cooperative form (shuffles inside a half-wave) for the small ones
         RowSet rs0 = make_rowset(*t, maxh);
-        if (rs0.count == 1 && rs0.width[0] >= 68 && leaf_wide_enabled())
+        if (rs0.count == 1 && rs0.width[0] >= 68 && rs0.stride[0] == rs0.width[0] && leaf_wide_enabled())
             hipLaunchKernelGGL(keccak_leaf_wide_kernel, dim3((uint32_t)((maxh + 255) / 256)), dim3(256), 0, stream, rs0.ptr[0], rs0.width[0], maxh,
                                t->layers);
-        else
+        else if (!launch_keccak_leaf_salted(stream, rs0, maxh, t->layers))
             hipLaunchKernelGGL(keccak_leaf_kernel, dim3((uint32_t)((maxh + 255) / 256)), dim3(256), 0, stream, rs0, maxh, t->layers);
         P3_HIP(hipGetLastError());
         for (size_t l = 1; l < t->layer_len.size(); l++) {
@@ -775,16 +866,17 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
     }
     {
         RowSet rs = make_rowset(*t, maxh);
-        if (rs.count == 1 && maxh < COOP_MAX && maxh * 16 <= 0x7fffffffull) {
+        const bool dense1 = rs.count == 1 && rs.stride[0] == rs.width[0];  // the single-matrix kernels take (pointer, width)
+        if (dense1 && maxh < COOP_MAX && maxh * 16 <= 0x7fffffffull) {
             hipLaunchKernelGGL(leaf_coop_kernel, dim3((uint32_t)((maxh * 16 + 255) / 256)), dim3(256), 0, stream, rs.ptr[0],
                                rs.width[0], (uint32_t)maxh, t->layers);
-        } else if (rs.count == 1 && use_f64_tree() && rs.width[0] >= 64 && leaf_wide_enabled()) {
+        } else if (dense1 && use_f64_tree() && rs.width[0] >= 64 && leaf_wide_enabled()) {
             hipLaunchKernelGGL(leaf_hash_f64_wide_kernel, dim3((uint32_t)((maxh + 255) / 256)), dim3(256), 0, stream, rs.ptr[0],
                                rs.width[0], maxh, t->layers);
-        } else if (rs.count == 1 && use_f64_tree()) {
+        } else if (dense1 && use_f64_tree()) {
             hipLaunchKernelGGL(leaf_hash_f64_kernel, dim3((uint32_t)((maxh + 255) / 256)), dim3(256), 0, stream, rs.ptr[0],
                                rs.width[0], maxh, t->layers);
-        } else if (use_f64_tree() && maxh >= COOP_MAX) {
+        } else if (use_f64_tree() && (maxh >= COOP_MAX || (rs.count == 1 && !dense1))) {
             hipLaunchKernelGGL(leaf_hash_f64_rowset_kernel, dim3((uint32_t)((maxh + 255) / 256)), dim3(256), 0, stream, rs, maxh, t->layers);
         } else {
             hipLaunchKernelGGL(leaf_hash_kernel, dim3((uint32_t)((maxh + 255) / 256)), dim3(256), 0, stream, rs, maxh, t->layers);
@@ -843,6 +935,7 @@ int mmcs_open(hipStream_t stream, const Tree& tc, uint64_t index, uint32_t* rows
     for (size_t m = 0; m < t.mats.size(); m++) {
         a.mat[m] = t.mats[m];
         a.width[m] = (uint32_t)t.widths[m];
+        a.stride[m] = (uint32_t)t.strides[m];
         a.shift[m] = t.log_max_height - log2u(t.heights[m]);
         row_words += t.widths[m];
     }

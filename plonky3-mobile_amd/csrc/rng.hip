@@ -24,6 +24,7 @@
 #include "common.h"
 #include "rng.h"
 
+#include <algorithm>
 #include <memory>
 #include <mutex>
 
@@ -255,43 +256,53 @@ __global__ void __launch_bounds__(256) rng_pass2_kernel(DevRng* st, const uint64
 // Pass 1 as above (jump, walk, count), but every candidate is kept: the wave's 64 lanes (= 64 chunks) produce one candidate each
 // per step; 32 steps fill a 64 x 32 tile in LDS, which goes out transposed — lanes 0..31 write 128 contiguous bytes of one
 // chunk, lanes 32..63 of the next — so raw[chunk][0..256) is written in whole 128-byte pieces instead of 4-byte words 1 KB apart.
+// SUB consecutive chunks per lane (template): the walk that hands every lane its first state costs ~80 wave-instructions per lane
+// (63 products per wave) — 20 per generated draw-step at one chunk per lane, as much as the draws themselves (25).  A lane that
+// simply keeps generating into its next chunk needs no product for it: at four chunks per lane the walk (over T^(4 CHUNK)) is 5 per
+// step.  More chunks per lane mean fewer waves, so the host picks the largest SUB that still leaves >= 1024 waves.
+template <uint32_t SUB_LOG>
 __global__ void __launch_bounds__(64) rng_gen_kernel(const DevRng* st, const uint64_t* __restrict__ jump, uint32_t n_chunks, uint32_t n_bits,
                                                      uint64_t* states, uint32_t* counts, uint32_t* raw) {
+    constexpr uint32_t SUB = 1u << SUB_LOG;
     __shared__ uint32_t tile[64 * 33];
-    const uint32_t lane = threadIdx.x, first = blockIdx.x * 64u, t = first + lane;
+    const uint32_t lane = threadIdx.x, first = blockIdx.x * (64u * SUB);  // the wave's first chunk; lane l owns first + l SUB ..+ SUB
     uint64_t cur[4] = {st->s[0], st->s[1], st->s[2], st->s[3]};
     to_interleaved(cur);
-    const LaneRows j0 = load_rows(jump);
-    for (uint32_t k = 6; k < n_bits; k++)
+    const LaneRows j0 = load_rows(jump + (size_t)SUB_LOG * 256 * 4);  // T^(CHUNK * SUB)
+    for (uint32_t k = 6 + SUB_LOG; k < n_bits; k++)
         if ((first >> k) & 1u) wave_matvec(load_rows(jump + (size_t)k * 256 * 4), cur);  // uniform branch
     uint64_t s[4] = {cur[0], cur[1], cur[2], cur[3]};
-    const uint32_t last = n_chunks - first < 64u ? n_chunks - first : 64u;  // chunks of this wave
+    const uint32_t left = n_chunks - first;
+    const uint32_t last = left < 64u * SUB ? (left + SUB - 1) / SUB : 64u;  // lanes of this wave that own a chunk
     for (uint32_t i = 1; i < last; i++) {
         wave_matvec(j0, cur);
         if (lane == i) { s[0] = cur[0]; s[1] = cur[1]; s[2] = cur[2]; s[3] = cur[3]; }
     }
     from_interleaved(s);
-    if (t < n_chunks) {
-#pragma unroll
-        for (int w = 0; w < 4; w++) states[(size_t)t * 4 + w] = s[w];
-    }
-    uint32_t cnt = 0;
     const uint32_t half = lane >> 5, col = lane & 31u;
-    for (uint32_t round = 0; round < RNG_CHUNK / 32; round++) {
+    for (uint32_t sc = 0; sc < SUB; sc++) {
+        const uint32_t t = first + lane * SUB + sc;
+        if (t < n_chunks) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) states[(size_t)t * 4 + w] = s[w];
+        }
+        uint32_t cnt = 0;
+        for (uint32_t round = 0; round < RNG_CHUNK / 32; round++) {
 #pragma unroll 4
-        for (uint32_t i = 0; i < 32; i++) {
-            const uint32_t v = (uint32_t)(xoshiro_next(s) >> 32) >> 1;
-            cnt += v < bb::P ? 1u : 0u;
-            tile[lane * 33 + i] = v;
+            for (uint32_t i = 0; i < 32; i++) {
+                const uint32_t v = (uint32_t)(xoshiro_next(s) >> 32) >> 1;
+                cnt += v < bb::P ? 1u : 0u;
+                tile[lane * 33 + i] = v;
+            }
+            __syncthreads();  // one wave per workgroup: orders the tile's writes before its transposed reads
+            for (uint32_t c = 0; c < 64; c += 2) {  // lane c's chunk on lanes 0..31, lane c + 1's on lanes 32..63
+                const uint32_t tc = first + (c + half) * SUB + sc;
+                if (tc < n_chunks) raw[((size_t)tc << RNG_CHUNK_LOG) + round * 32 + col] = tile[(c + half) * 33 + col];
+            }
+            __syncthreads();
         }
-        __syncthreads();  // one wave per workgroup: orders the tile's writes before its transposed reads
-        for (uint32_t c = 0; c < 64; c += 2) {  // chunk c on lanes 0..31, chunk c + 1 on lanes 32..63
-            const uint32_t ch = c + half;
-            if (ch < last) raw[((size_t)(first + ch) << RNG_CHUNK_LOG) + round * 32 + col] = tile[ch * 33 + col];
-        }
-        __syncthreads();
+        if (t < n_chunks) counts[t] = cnt;
     }
-    if (t < n_chunks) counts[t] = cnt;
 }
 // Pass 2: one wave per chunk.  Lane l holds candidates 4l .. 4l+3 (one 16-byte load), a wave scan of the acceptance counts gives
 // every accepted value its place, neighbours write neighbours.  The lane that holds the n-th element of the fill replays its chunk
@@ -391,7 +402,13 @@ int rng_fill_field(Context& cx, hipStream_t stream, DevRng* st, uint32_t* out, u
     if (!two_pass) {
         // raw candidates behind the block totals, 16-byte aligned
         uint32_t* raw = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(bsum + tiles + 1) + 15u) & ~(uintptr_t)15u);
-        hipLaunchKernelGGL(rng_gen_kernel, dim3((chunks + 63) / 64), dim3(64), 0, stream, st, cx.rng_jump, chunks, n_bits, states, counts, raw);
+        // chunks per lane: the most that still leaves the chip >= 1024 waves (P3HIP_RNG_SUB_LOG forces 0..2)
+        static const int sub_env = [] { const char* e = getenv("P3HIP_RNG_SUB_LOG"); return e ? atoi(e) : -1; }();
+        const uint32_t sub_log = sub_env >= 0 ? (uint32_t)std::min(sub_env, 2) : (chunks >= (1024u * 64u * 4u) ? 2u : chunks >= (1024u * 64u * 2u) ? 1u : 0u);
+        const dim3 grid((chunks + (64u << sub_log) - 1) / (64u << sub_log));
+        if (sub_log == 2) hipLaunchKernelGGL(rng_gen_kernel<2>, grid, dim3(64), 0, stream, st, cx.rng_jump, chunks, n_bits, states, counts, raw);
+        else if (sub_log == 1) hipLaunchKernelGGL(rng_gen_kernel<1>, grid, dim3(64), 0, stream, st, cx.rng_jump, chunks, n_bits, states, counts, raw);
+        else hipLaunchKernelGGL(rng_gen_kernel<0>, grid, dim3(64), 0, stream, st, cx.rng_jump, chunks, n_bits, states, counts, raw);
         P3_HIP(hipGetLastError());
         hipLaunchKernelGGL(rng_scan_tiles_kernel, dim3(tiles), dim3(256), 0, stream, counts, chunks, bsum);
         P3_HIP(hipGetLastError());

@@ -32,6 +32,40 @@ def test_gpus_2_starts_two_ranks_and_gathers_on_rank_0():
     assert out["collectives"].startswith("gloo scatter/gather")
     assert out["cpu_baseline"].startswith("omitted for world > 1")
     assert "STUB" in out["metric"] and "STUB" in out["data"]  # a stub line can not pass for a measurement
+    # the line explains itself per rank (round-3 review, item 4): work done, own wall time, where it waited, host cores
+    for r in out["ranks"]:
+        assert r["proofs"] == 32 * 3 and r["prove_wall_s"] > 0 and r["proofs_per_s"] > 0
+        for k in ("scatter_wait_s", "gather_wait_s", "prover_join_s"):
+            assert r[k] >= 0.0
+        assert r["host_cores"] >= 1 and r["pinned"] in (0, 1)
+    assert out["ranks"][0]["pinning"] and out["ranks"][0]["host_core_list"]
+    assert out["gather_bytes_per_step"] == 64 * 64  # 64 stub proofs of 64 bytes per step
+
+
+def test_ranks_pin_to_the_cores_local_to_their_gpu_when_the_list_is_readable():
+    """P3HIP_BENCH_PIN_CPULIST stands in for /sys/bus/pci/devices/<bdf>/local_cpulist: every rank narrows its affinity mask to the
+    listed cores that are inside the launcher's mask and says so; an unreadable / disjoint list changes nothing."""
+    have = sorted(os.sched_getaffinity(0))
+    res = _bench(["--gpus", "2", "--steps", "2", "--warmup", "0"],
+                 {"P3HIP_BENCH_STUB": "1", "P3HIP_BENCH_BACKEND": "gloo", "P3HIP_BENCH_PIN_CPULIST": "%d,100000-100003" % have[0]})
+    assert res.returncode == 0, res.stderr
+    out = _line(res)
+    assert [r["host_cores"] for r in out["ranks"]] == [1, 1] and [r["pinned"] for r in out["ranks"]] == [1, 1]
+    assert out["ranks"][0]["pinning"].startswith("pinned to the 1 core") and out["ranks"][0]["host_core_list"] == str(have[0])
+    res = _bench(["--gpus", "2", "--steps", "2", "--warmup", "0"],
+                 {"P3HIP_BENCH_STUB": "1", "P3HIP_BENCH_BACKEND": "gloo", "P3HIP_BENCH_PIN_CPULIST": "100000-100003"})
+    out = _line(res)
+    assert [r["pinned"] for r in out["ranks"]] == [0, 0] and out["ranks"][0]["host_cores"] == len(have)
+    assert out["ranks"][0]["pinning"].startswith("none (")
+
+
+def test_cpulist_parser():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert bench.parse_cpulist("") == set()
 
 
 def test_cfg4_is_64_proofs_in_total_split_over_the_ranks():
@@ -49,6 +83,9 @@ def test_single_rank_line_is_not_distributed():
     out = _line(res)
     assert out["n_gpus"] == 1 and out["world_size"] == 1 and out["dist_backend"] is None and len(out["ranks"]) == 1
     assert out["config"]["batch_per_gpu"] == 64
+    r = out["ranks"][0]
+    assert r["proofs"] == 128 and r["prove_wall_s"] > 0 and r["gather_wait_s"] == 0.0 and r["scatter_wait_s"] == 0.0
+    assert r["pinning"].startswith("none (single rank") and out["gather_bytes_per_step"] == 0
 
 
 def test_refuses_more_ranks_than_gpus_on_the_rccl_backend():

@@ -126,40 +126,50 @@ def cpu_baseline_wide(job):
 HOST_CORES, PINNING = [], "not evaluated"
 
 
-def other_workloads():
+def other_workloads(budget_s=240.0, child_timeout_s=120.0):
     """The default run (what the driver records) also carries SHORT runs of the other single-GPU BASELINE configs and of the
     reference's own configuration, so that their numbers are in a driver-run record and not only in builder-run profiles:
-    each is this same script in a child process (`--no-cpu-baseline --no-extras`, few steps), its line condensed.  A child
-    that fails leaves its error text; the main line does not depend on them."""
+    each is this same script in a child process (`--no-cpu-baseline --no-extras`, few steps), its line condensed to a few
+    numbers (the entries are the LAST thing in the line, the two BASELINE configs last of all, so that a reader who keeps only
+    the tail of the line still sees them).  A child gets at most `child_timeout_s`; once `budget_s` is spent the remaining ones
+    are recorded as skipped.  A child that fails leaves its error text; the main line does not depend on them."""
     import subprocess
-    runs = [("cfg3", ["--workload", "cfg3", "--steps", "2", "--warmup", "1"]),
-            ("cfg5", ["--workload", "cfg5", "--steps", "6", "--warmup", "2"]),
-            ("cfg2 under the reference's Keccak hashes", ["--hash", "keccak", "--steps", "6", "--warmup", "1"]),
-            ("the reference's own configuration (Keccak + hiding), 2^20 rows", ["--hash", "keccak", "--hiding", "--steps", "3", "--warmup", "1"])]
+    runs = [("cfg2 under the reference's Keccak hashes", ["--hash", "keccak", "--steps", "6", "--warmup", "1"]),
+            ("the reference's own configuration (Keccak + hiding), 2^20 rows", ["--hash", "keccak", "--hiding", "--steps", "3", "--warmup", "1"]),
+            ("cfg3", ["--workload", "cfg3", "--steps", "2", "--warmup", "1"]),
+            ("cfg5", ["--workload", "cfg5", "--steps", "6", "--warmup", "2"])]
     res = []
+    t_all = time.perf_counter()
     for label, extra in runs:
         t0 = time.perf_counter()
-        entry = {"label": label, "command": "python bench.py " + " ".join(extra) + " --no-cpu-baseline --no-extras"}
+        entry = {"label": label, "args": " ".join(extra)}
+        left = budget_s - (t0 - t_all)
+        if left < 20.0:
+            entry["skipped"] = "time budget of the extras spent"
+            res.append(entry)
+            continue
         try:
             p = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra + ["--no-cpu-baseline", "--no-extras"],
-                               capture_output=True, text=True, timeout=300)
+                               capture_output=True, text=True, timeout=min(child_timeout_s, left))
             lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
             if p.returncode != 0 or not lines:
-                entry["error"] = "exit code %d: %s" % (p.returncode, p.stderr.strip()[-300:])
+                entry["error"] = "exit code %d: %s" % (p.returncode, p.stderr.strip()[-200:])
             else:
                 d = json.loads(lines[-1])
-                entry.update({k: d[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step") if k in d})
-                entry["workload"] = d["config"]["workload"]
-                r = d.get("roofline") or {}
-                entry["roofline"] = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_us", "algorithmic_bytes", "kernel")}
-                v = d.get("valu_roofline") or {}
+                r, v = d.get("roofline") or {}, d.get("valu_roofline") or {}
+                rnd = lambda x, n=4: round(x, n) if isinstance(x, (int, float)) else x  # noqa: E731
+                entry.update({"value": rnd(d.get("value"), 2), "unit": d.get("unit"), "steps": d.get("steps"),
+                              "lde_us": rnd(r.get("avg_us"), 1), "lde_gbps": rnd(r.get("achieved"), 1), "lde_frac": rnd(r.get("frac")),
+                              "lde_valu_frac": rnd(r.get("valu_frac")), "lde_traffic": r.get("traffic")})
                 if v:
-                    entry["valu_roofline"] = {k: v.get(k) for k in ("hash", "achieved", "frac", "instructions_per_permutation", "sustained_gperm_s",
-                                                                    "kernel_ceiling_gperm_s", "sustained_frac_of_kernel_ceiling")}
+                    entry.update({"hash_valu_busy": rnd(v.get("frac")), "sustained_gperm_s": rnd(v.get("sustained_gperm_s"), 3),
+                                  "sustained_frac_of_kernel_ceiling": rnd(v.get("sustained_frac_of_kernel_ceiling"))})
                 if "commit" in r:
-                    entry["roofline"]["commit"] = r["commit"]
+                    entry["commit_gperm_s"] = rnd(r["commit"].get("gperm_s"), 3)
+        except subprocess.TimeoutExpired:
+            entry["error"] = "timed out after %.0f s" % min(child_timeout_s, left)
         except Exception as e:  # noqa: BLE001
-            entry["error"] = repr(e)
+            entry["error"] = repr(e)[:200]
         entry["wall_s"] = round(time.perf_counter() - t0, 1)
         res.append(entry)
     return res
@@ -206,8 +216,8 @@ def pin_to_gpu_local_cores(torch, device_index, world, sysfs="/sys/bus/pci/devic
 
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` with no launcher around it: start N fresh rank processes (one per GPU) with
-    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relay rank 0's JSON line, return the worst exit code.  This parent has
-    not touched the GPU (torch.cuda.device_count() does not initialise it on this image) and never execs."""
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relay rank 0's JSON line, return the worst exit code.  This parent runs no
+    kernel and never execs (it only counts devices; the ranks are fresh child processes either way)."""
     import socket
     import subprocess
     backend = os.environ.get("P3HIP_BENCH_BACKEND", "nccl")

@@ -189,8 +189,11 @@ int p3hip_fib_prover_create(unsigned log_n, const p3hip_fri_params_t *params, vo
  * Wire format: DESIGN.md "proof bytes". */
 int p3hip_fib_prover_prove(p3hip_fib_prover_t *prover, uint64_t a, uint64_t b, const uint8_t **proof_out,
                            size_t *proof_len);
-/* The same with the proof written into the CALLER's buffer (e.g. the pinned staging row of a gather): returns ERR_BAD_ARG when
- * cap is too small (the needed size in *proof_len).  Saves the host two copies per proof when the bytes travel on. */
+/* The same with the proof handed over in the CALLER's buffer (e.g. the pinned staging row of a gather): the prover serialises
+ * into its own buffer and copies ONCE into `out` (what is saved are the caller-side copies — a Python bytes object and its copy
+ * into the staging row).  Returns ERR_BAD_ARG when cap is too small, the needed size in *proof_len: checked BEFORE proving once
+ * the prover has produced a proof (proofs of one prover have one length); on a first call that fails this way the proof has been
+ * computed and discarded.  A retry returns the same bytes (the hiding prover restarts its streams from the seed for every proof). */
 int p3hip_fib_prover_prove_into(p3hip_fib_prover_t *prover, uint64_t a, uint64_t b, uint8_t *out, size_t cap, size_t *proof_len);
 /* The same in two halves, to keep the prover's stream busy across proofs: enqueue returns as soon as the proof's launches
  * are queued (nothing is waited for), finish waits for the OLDEST enqueued proof and returns its bytes (valid until the next

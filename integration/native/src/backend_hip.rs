@@ -30,6 +30,16 @@ extern "C" {
         shift_monty: u32,
         bit_reversed_out: i32,
     ) -> i32;
+    fn p3hip_coset_lde_batch_bb31_dev(
+        d_in: *const u32,
+        d_out: *mut u32,
+        height: usize,
+        width: usize,
+        added_bits: u32,
+        shift_monty: u32,
+        bit_reversed_out: i32,
+        stream: *mut core::ffi::c_void,
+    ) -> i32;
 }
 
 fn last_error() -> String {
@@ -86,9 +96,32 @@ fn call<F: TwoAdicField>(
     Ok(RowMajorMatrix::new(out, w))
 }
 
-pub fn dft_batch<F: TwoAdicField>(_cpu: &Radix2DitParallel<F>, mat: RowMajorMatrix<F>) -> Result<RowMajorMatrix<F>, String> {
+pub fn dft_batch<F: TwoAdicField + Ord>(cpu: &Radix2DitParallel<F>, mat: RowMajorMatrix<F>) -> Result<RowMajorMatrix<F>, String> {
     let h = mat.height();
-    call(&mat, h, |i, o, h, w| unsafe { p3hip_dft_batch_bb31(i, o, h, w) })
+    // the reference's debug self-check (native/src/backend_vulkan.rs:2008-2057): debug builds keep the prover's live input,
+    // run Plonky3's CPU DFT beside the device and compare — tolerant, like the reference, of a result whose ROWS are
+    // bit-reversed (backend_vulkan.rs:2034-2050) — and turn a mismatch into Err, i.e. CPU fallback + mailbox message
+    #[cfg(debug_assertions)]
+    let input = mat.clone();
+    let out = call(&mat, h, |i, o, h, w| unsafe { p3hip_dft_batch_bb31(i, o, h, w) })?;
+    #[cfg(debug_assertions)]
+    {
+        use p3_dft::TwoAdicSubgroupDft;
+        use p3_matrix::bitrev::BitReversibleMatrix;
+        let expected = cpu.dft_batch(input).to_row_major_matrix();
+        if out.values != expected.values {
+            let rev = expected.clone().bit_reverse_rows().to_row_major_matrix();
+            let first = out.values.iter().zip(expected.values.iter()).position(|(a, b)| a != b).unwrap_or(0);
+            return Err(if out.values == rev.values {
+                format!("hip dft_batch: output rows are bit-reversed relative to Radix2DitParallel (h={h}, w={})", out.width())
+            } else {
+                format!("hip dft_batch: mismatch against Radix2DitParallel at word {first} (h={h}, w={})", out.width())
+            });
+        }
+    }
+    #[cfg(not(debug_assertions))]
+    let _ = cpu;
+    Ok(out)
 }
 
 pub fn idft_batch<F: TwoAdicField>(mat: RowMajorMatrix<F>) -> Result<RowMajorMatrix<F>, String> {
@@ -111,4 +144,29 @@ pub fn coset_lde_batch<F: TwoAdicField>(mat: RowMajorMatrix<F>, added_bits: usiz
     let h = mat.height();
     let s = unsafe { *(&shift as *const F as *const u32) };
     call(&mat, h << added_bits, |i, o, h, w| unsafe { p3hip_coset_lde_batch_bb31(i, o, h, w, added_bits as u32, s, 0) })
+}
+
+/// The same LDE with the result LEFT IN HBM (hip_matrix.rs): upload the evaluations, run the transform with bit-reversed STORAGE
+/// (what `TwoAdicFriPcs::commit` commits), return a `HipMatrix` labelled `BitReversed`, i.e. presenting the natural order the
+/// trait specifies.  The PCS's `.bit_reverse_rows()` is then a relabelling, and `.to_row_major_matrix()` is the one download of
+/// the trait path, which registers the device copy for `HipMmcs::commit`.
+pub fn coset_lde_batch_resident<F: TwoAdicField>(
+    mat: RowMajorMatrix<F>,
+    added_bits: usize,
+    shift: F,
+) -> Result<crate::hip_matrix::HipMatrix<F>, String> {
+    use crate::hip_matrix::{HipMatrix, RowOrder};
+    require_babybear::<F>()?;
+    let (h, w) = (mat.height(), mat.width());
+    if !h.is_power_of_two() {
+        return Err(format!("hip backend requires power-of-two height, got {h}"));
+    }
+    let s = unsafe { *(&shift as *const F as *const u32) };
+    let input = HipMatrix::from_host(&mat)?;
+    let out = HipMatrix::<F>::alloc(h << added_bits, w, RowOrder::BitReversed)?;
+    let rc = unsafe { p3hip_coset_lde_batch_bb31_dev(input.device_ptr(), out.device_ptr_mut(), h, w, added_bits as u32, s, 1, core::ptr::null_mut()) };
+    if rc != 0 {
+        return Err(last_error());
+    }
+    Ok(out)
 }

@@ -31,6 +31,8 @@ fn text_of(buf: &[c_char]) -> String {
 fn into_result(text: String, prefix: &str) -> Result<String, String> {
     match text.strip_prefix(prefix) {
         Some(err) => Err(err.to_string()),
+        // an otherwise-ok report may carry a trailing "\nHIP error: .." (a message left in the mailbox by a call that then fell
+        // back): it stays part of the Ok text, exactly as lib.rs:60-75 appends "\nVulkan error: .." to a SUCCESSFUL report
         None => Ok(text),
     }
 }
@@ -46,7 +48,8 @@ pub fn run_fib_air_zk_hip() -> Result<String, String> {
 unsafe extern "C" fn cpu_dft_cb(user: *mut c_void, input: *const u32, out: *mut u32, height: usize, width: usize) -> i32 {
     let cpu = &*(user as *const GpuDft<Val>);
     let src = core::slice::from_raw_parts(input as *const Val, height * width);
-    let res = std::panic::catch_unwind(|| cpu.dft_batch(RowMajorMatrix::new(src.to_vec(), width)));
+    // GpuDft holds no interior state a panic could leave half-updated; the closure borrows it and a fresh Vec
+    let res = std::panic::catch_unwind(std::panic::AssertUnwindSafe(|| cpu.dft_batch(RowMajorMatrix::new(src.to_vec(), width)).to_row_major_matrix()));
     match res {
         Ok(m) => {
             core::ptr::copy_nonoverlapping(m.values.as_ptr() as *const u32, out, height * width);

@@ -45,6 +45,16 @@ extern "C" {
         root_out: *mut u32,
         tree_out: *mut *mut p3hip_tree_t,
     ) -> i32;
+    fn p3hip_mmcs_commit_hash_dev(
+        hash: i32,
+        d_mats: *const *const u32,
+        heights: *const usize,
+        widths: *const usize,
+        n_mats: usize,
+        root_out: *mut u32,
+        tree_out: *mut *mut p3hip_tree_t,
+        stream: *mut c_void,
+    ) -> i32;
     fn p3hip_malloc(dev_ptr: *mut *mut c_void, bytes: usize) -> i32;
     fn p3hip_free(dev_ptr: *mut c_void) -> i32;
     fn p3hip_upload(dev_dst: *mut c_void, host_src: *const c_void, bytes: usize) -> i32;
@@ -83,6 +93,8 @@ pub struct HipTree<M> {
     handle: *mut p3hip_tree_t,
     mats: Vec<M>,
     widths: Vec<usize>,
+    /// device copies the tree was built over when every input was already resident (hip_matrix.rs): kept alive with the tree
+    resident: Vec<crate::hip_matrix::ResidentWords>,
 }
 unsafe impl<M: Send> Send for HipTree<M> {}
 unsafe impl<M: Sync> Sync for HipTree<M> {}
@@ -148,13 +160,36 @@ where
 
     fn commit<M: Matrix<BabyBear>>(&self, inputs: Vec<M>) -> (Self::Commitment, Self::ProverData<M>) {
         assert_eq!(N, W::DIGEST_ELEMS);
-        // row-major Montgomery words of every matrix (BabyBear is repr(transparent) over u32)
-        let dense: Vec<RowMajorMatrix<BabyBear>> = inputs.iter().map(|m| m.to_row_major_matrix()).collect();
-        let ptrs: Vec<*const u32> = dense.iter().map(|m| m.values.as_ptr() as *const u32).collect();
-        let heights: Vec<usize> = dense.iter().map(|m| m.height()).collect();
-        let widths: Vec<usize> = dense.iter().map(|m| m.width()).collect();
+        let heights: Vec<usize> = inputs.iter().map(|m| m.height()).collect();
+        let widths: Vec<usize> = inputs.iter().map(|m| m.width()).collect();
         let mut root = [0u32; 8];
         let mut handle: *mut p3hip_tree_t = core::ptr::null_mut();
+        // Resident inputs: a dense host matrix that `HipMatrix::to_row_major_matrix` downloaded (what TwoAdicFriPcs::commit hands
+        // over after GpuDft's hip arm produced the LDE) still has its device copy registered under the address of its words.
+        // `row_slice(0)` of a dense matrix derefs into those words; of any other matrix type into a temporary, which is simply
+        // not in the registry.  When EVERY input is resident the tree is built over the device copies: no upload at all.
+        let resident: Vec<crate::hip_matrix::ResidentWords> = inputs
+            .iter()
+            .filter_map(|m| {
+                if m.height() == 0 {
+                    return None;
+                }
+                let first = m.row_slice(0);
+                crate::hip_matrix::take_resident(first.as_ptr() as usize, m.height() * m.width())
+            })
+            .collect();
+        if resident.len() == inputs.len() {
+            let ptrs: Vec<*const u32> = resident.iter().map(|r| r.device_ptr()).collect();
+            let rc = unsafe {
+                p3hip_mmcs_commit_hash_dev(W::HASH_KIND, ptrs.as_ptr(), heights.as_ptr(), widths.as_ptr(), inputs.len(), root.as_mut_ptr(), &mut handle, core::ptr::null_mut())
+            };
+            assert!(rc == 0, "hip mmcs commit failed: {}", last_error());
+            let digest: [W; N] = W::from_words(&root).try_into().ok().expect("digest length");
+            return (Hash::from(digest), HipTree { handle, mats: inputs, widths, resident });
+        }
+        // otherwise: row-major Montgomery words of every matrix (BabyBear is repr(transparent) over u32), uploaded by the library
+        let dense: Vec<RowMajorMatrix<BabyBear>> = inputs.iter().map(|m| RowMajorMatrix::new(m.rows().flatten().collect(), m.width())).collect();
+        let ptrs: Vec<*const u32> = dense.iter().map(|m| m.values.as_ptr() as *const u32).collect();
         let rc = unsafe {
             p3hip_mmcs_commit_hash(W::HASH_KIND, ptrs.as_ptr(), heights.as_ptr(), widths.as_ptr(), dense.len(), root.as_mut_ptr(), &mut handle)
         };
@@ -162,7 +197,7 @@ where
         // other prover panic (native/src/lib.rs:45-59)
         assert!(rc == 0, "hip mmcs commit failed: {}", last_error());
         let digest: [W; N] = W::from_words(&root).try_into().ok().expect("digest length");
-        (Hash::from(digest), HipTree { handle, mats: inputs, widths })
+        (Hash::from(digest), HipTree { handle, mats: inputs, widths, resident: Vec::new() })
     }
 
     fn open_batch<M: Matrix<BabyBear>>(&self, index: usize, prover_data: &Self::ProverData<M>) -> BatchOpening<BabyBear, Self> {

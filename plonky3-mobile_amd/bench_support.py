@@ -18,6 +18,30 @@ from .gpu_dft import GENERATOR_MONTY, BackendKind, GpuDft, _stream_ptr
 from .mmcs import MerkleTreeMmcs
 
 
+def lde_valu_view(key, unit_us, algorithmic_bytes):
+    """The coset-LDE unit against the roofline that actually binds it from ~2^21 rows on: VALU issue.  `key` = cfg2 | cfg3 | cfg5 in
+    profiles/r04_pmc_lde_valu.json (SQ_INSTS_VALU of the unit's launches, tools/r04_lde_valu.sh).  valu_frac = wave-instructions of
+    the unit / measured unit time / the chip's measured issue rate (36 T lane-ops/s = 562.5 G wave-instructions/s,
+    profiles/r01_microbench2_valu_issue_rates.txt); hbm_frac_ceiling_at_this_instruction_count = the best HBM fraction this many
+    instructions allow, i.e. algorithmic bytes / (instructions / issue rate) / 8 TB/s."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        with open(os.path.join(root, "profiles", "r04_pmc_lde_valu.json")) as f:
+            pmc = json.load(f)
+        e = pmc[key]
+        peak = pmc.get("peak_wave_instr_per_s", 36e12 / 64)
+        wi = e["unit_valu_wave_instr"]
+        return {"valu_frac": wi / (unit_us * 1e-6) / peak,
+                "valu_wave_instructions_per_unit": wi,
+                "valu_instructions_per_butterfly": e["valu_lane_instr_per_butterfly"],
+                "valu_peak": "36 T lane-ops/s measured (profiles/r01_microbench2_valu_issue_rates.txt)",
+                "hbm_frac_ceiling_at_this_instruction_count": algorithmic_bytes / (wi / peak) / 8e12,
+                "valu_source": "profiles/r04_pmc_lde_valu.json (rocprofv3 --pmc SQ_INSTS_VALU over the unit's launches)"}
+    except Exception:
+        return {"valu_frac": None, "valu_source": None}
+
+
 class _Worker(threading.Thread):
     def __init__(self, device, log_height, params, stagger_s=0.0, hash="poseidon2", hiding=False):
         super().__init__(daemon=True)
@@ -156,11 +180,15 @@ class FibAirJob:
                     break
             except Exception:
                 continue
-        return {"bound": "hbm", "achieved": roof["gbps"], "peak": 8000.0, "unit": "GB/s", "frac": roof["gbps"] / 8000.0,
-                "frac_of_achievable_6300": roof["gbps"] / 6300.0, "traffic": traffic, "traffic_source": src,
-                "kernel": "coset_lde_batch (narrow plan: one unit of " + str(roof.get("launches", "3")) + " launches)",
-                "algorithmic_bytes": roof["bytes"], "avg_us": roof["avg_us"],
-                "concurrent_gbps": roof.get("concurrent_gbps"), "concurrent_streams": roof.get("concurrent_streams")}
+        out = {"bound": "hbm", "achieved": roof["gbps"], "peak": 8000.0, "unit": "GB/s", "frac": roof["gbps"] / 8000.0,
+               "frac_of_achievable_6300": roof["gbps"] / 6300.0, "traffic": traffic, "traffic_source": src,
+               "kernel": "coset_lde_batch (narrow plan: one unit of " + str(roof.get("launches", "3")) + " launches)",
+               "algorithmic_bytes": roof["bytes"], "avg_us": roof["avg_us"],
+               "concurrent_gbps": roof.get("concurrent_gbps"), "concurrent_streams": roof.get("concurrent_streams")}
+        key = {(20, 1): "cfg2", (24, 2): "cfg3"}.get((self.log_height, self.log_blowup))
+        if key:
+            out.update(lde_valu_view(key, roof["avg_us"], roof["bytes"]))
+        return out
 
     def extra_report(self):
         out = {"valu_roofline": self.hash_roofline()}
@@ -505,6 +533,7 @@ class WideCommitJob:
                 "frac": lde_bytes / (t_lde * 1e-3) / 1e9 / 8000.0,
                 "frac_of_achievable_6300": lde_bytes / (t_lde * 1e-3) / 1e9 / 6300.0,
                 "algorithmic_bytes": lde_bytes, "avg_us": t_lde * 1e3, "traffic": traffic, "traffic_source": src,
+                **(lde_valu_view("cfg5", t_lde * 1e3, lde_bytes) if (self.log_height, self.width, self.log_blowup) == (16, 2633, 1) else {}),
                 "commit": {"bound": "valu (hash)", "algorithmic_bytes": commit_bytes, "avg_us": t_commit * 1e3,
                            "achieved_gbps": commit_bytes / (t_commit * 1e-3) / 1e9, "permutations": perms,
                            "gperm_s": perms / (t_commit * 1e-3) / 1e9}}

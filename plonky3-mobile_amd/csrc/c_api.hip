@@ -498,6 +498,11 @@ int p3hip_fib_prover_prove(p3hip_fib_prover_t* prover, uint64_t a, uint64_t b, c
 int p3hip_fib_prover_prove_into(p3hip_fib_prover_t* prover, uint64_t a, uint64_t b, uint8_t* out, size_t cap, size_t* proof_len) {
     return guarded([&]() -> int {
         if (!prover || !out || !proof_len) return fail(ERR_BAD_ARG, "fib_prover_prove_into: null argument");
+        // proofs of one prover have one length: once it is known, a buffer that cannot hold it fails BEFORE any work is queued
+        if (!prover->last.empty() && prover->last.size() > cap) {
+            *proof_len = prover->last.size();
+            return fail(ERR_BAD_ARG, "fib_prover_prove_into: the proof needs " + std::to_string(prover->last.size()) + " bytes");
+        }
         int rc = prover->hiding ? prover->hiding->prove(a, b, &prover->last) : prover->plain->prove(a, b, &prover->last);
         if (rc) return rc;
         *proof_len = prover->last.size();

@@ -82,9 +82,13 @@ __device__ __forceinline__ void permute(uint64_t (&a)[25]) {
 // Keccak-f when only the first four words of the result are wanted (a digest: every MMCS hash and compression): the
 // last round computes just row y = 0, which needs theta on the diagonal a[0], a[6], a[12], a[18], a[24], four rotations
 // and four chi words — 58 VALU instructions instead of 180.  Words 4..24 of `a` are left unspecified.
+// The FIRST round is peeled out of the rolled loop: every caller absorbs one block into a zeroed state, so at least eight of
+// the 25 words entering it are compile-time zeros (17 for a compression, 19-20 for a salted leaf) and theta folds — column
+// parities of one or two words, a[x, y] ^ D[x] = D[x] for the zero words — 142 instead of 180 instructions for a compression.
 __device__ __forceinline__ void permute_digest(uint64_t (&a)[25]) {
+    round(a, 0x0000000000000001ULL);
     _Pragma("clang loop unroll(disable)")
-    for (int r = 0; r < 23; r++) round(a, d_rc[r]);
+    for (int r = 1; r < 23; r++) round(a, d_rc[r]);
     uint64_t c[5], b[5];
 #pragma unroll
     for (int x = 0; x < 5; x++) c[x] = xor3(xor3(a[x], a[x + 5], a[x + 10]), a[x + 15], a[x + 20]);

@@ -129,9 +129,14 @@ def test_other_workloads_condenses_child_lines_and_survives_a_failing_child(monk
     res = bench.other_workloads()
     assert len(res) == 4 and len(calls) == 4
     assert all("--no-cpu-baseline" in c and "--no-extras" in c for c in calls)  # a child never recurses into extras
+    assert [e["label"] for e in res][-2:] == ["cfg3", "cfg5"]  # the BASELINE configs last: they must survive a tail of the line
     ok = [e for e in res if "error" not in e]
     bad = [e for e in res if "error" in e]
-    assert len(ok) == 3 and len(bad) == 1 and "boom" in bad[0]["error"] and "cfg5" in bad[0]["command"]
+    assert len(ok) == 3 and len(bad) == 1 and "boom" in bad[0]["error"] and "cfg5" in bad[0]["args"]
     e = ok[0]
-    assert e["value"] == 19.1 and e["roofline"]["frac"] == 0.092 and e["roofline"]["commit"] == {"gperm_s": 7.5}
-    assert e["valu_roofline"]["frac"] == 0.97 and e["workload"] == "fib_air 2^24-row trace"
+    assert e["value"] == 19.1 and e["lde_frac"] == 0.092 and e["commit_gperm_s"] == 7.5 and e["lde_us"] == 912.0
+    assert e["hash_valu_busy"] == 0.97 and e["sustained_gperm_s"] == 7.7
+    assert len(json.dumps(res)) < 1900  # all four entries fit the last 2000 bytes of the line
+    # a spent budget records the rest as skipped instead of starting children
+    res = bench.other_workloads(budget_s=0.0)
+    assert all("skipped" in e for e in res) and len(calls) == 4

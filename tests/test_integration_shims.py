@@ -45,7 +45,10 @@ def test_rust_shims_bind_the_declared_c_abi():
                 seen.add(name)
     # the shims cover the boundary the reference needs: the DFT entry, the LDE, the MMCS and the diagnostics
     for must in ("p3hip_dft_batch_bb31", "p3hip_coset_lde_batch_bb31", "p3hip_mmcs_commit_hash", "p3hip_mmcs_open_batch",
-                 "p3hip_mmcs_free", "p3hip_take_last_error", "p3hip_is_available", "p3hip_run_fib_air_zk", "p3hip_run_dft_benchmark"):
+                 "p3hip_mmcs_free", "p3hip_take_last_error", "p3hip_is_available", "p3hip_run_fib_air_zk", "p3hip_run_dft_benchmark",
+                 # round 4: the LDE left in HBM and found again by the commit (hip_matrix.rs, backend_hip.rs, hip_mmcs.rs)
+                 "p3hip_coset_lde_batch_bb31_dev", "p3hip_mmcs_commit_hash_dev", "p3hip_download", "p3hip_upload", "p3hip_malloc",
+                 "p3hip_free", "p3hip_bit_reverse_rows_dev"):
         assert must in seen, must
 
 
@@ -83,3 +86,22 @@ def test_fib_air_patch_makes_the_prover_honour_the_selector():
                    "Radix2DitParallel", 'strip_prefix(prefix)'):
         assert needle in front, needle
     assert "mod hip_front_end;" in open(os.path.join(INTEG, "native", "src", "lib.rs.patch")).read()
+
+
+def test_trait_path_keeps_the_lde_resident_and_carries_the_debug_self_check():
+    """Round-3 review, item 8: `GpuDft::Evaluations` on the hip arm is a device matrix, the PCS's download registers the device copy,
+    `HipMmcs::commit` takes it instead of uploading; and backend_hip.rs has the reference's debug compare (backend_vulkan.rs:2008-2057)."""
+    src = os.path.join(INTEG, "native", "src")
+    mat = open(os.path.join(src, "hip_matrix.rs")).read()
+    for needle in ("pub struct HipMatrix<F>", "impl<F: Field> Matrix<F> for HipMatrix<F>", "impl<F: Field> BitReversibleMatrix<F> for HipMatrix<F>",
+                   "pub enum GpuEvaluations<F>", "pub fn take_resident(", "register_resident(", "RowOrder::BitReversed", "p3hip_download("):
+        assert needle in mat, needle
+    patch = open(os.path.join(src, "gpu_dft.rs.patch")).read()
+    assert "type Evaluations = GpuEvaluations<F>;" in patch and "-    type Evaluations = RowMajorMatrix<F>;" in patch
+    assert "backend_hip::coset_lde_batch_resident(" in patch and "GpuEvaluations::Device(result)" in patch
+    mmcs = open(os.path.join(src, "hip_mmcs.rs")).read()
+    assert "crate::hip_matrix::take_resident(" in mmcs and "p3hip_mmcs_commit_hash_dev(" in mmcs
+    hip = open(os.path.join(src, "backend_hip.rs")).read()
+    assert "#[cfg(debug_assertions)]" in hip and "cpu.dft_batch(input)" in hip and "bit_reverse_rows()" in hip
+    assert "p3hip_coset_lde_batch_bb31_dev(" in hip and "RowOrder::BitReversed" in hip
+    assert "mod hip_matrix;" in open(os.path.join(src, "lib.rs.patch")).read()

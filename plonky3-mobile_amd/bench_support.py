@@ -168,7 +168,7 @@ class FibAirJob:
         roof = self.lde_roofline(reps=20)
         traffic, src = None, None
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        for name in ("r03_pmc_lde.json", "r02_pmc_lde.json", "r01_pmc_lde_v2.json"):
+        for name in ("r04_pmc_lde.json", "r03_pmc_lde.json", "r02_pmc_lde.json", "r01_pmc_lde_v2.json"):
             try:
                 with open(os.path.join(root, "profiles", name)) as f:
                     pmc = json.load(f)
@@ -517,15 +517,17 @@ class WideCommitJob:
         try:
             import json
             root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-            with open(os.path.join(root, "profiles", "r03_pmc_lde.json")) as f:
+            name = "r04_pmc_lde.json" if os.path.exists(os.path.join(root, "profiles", "r04_pmc_lde.json")) else "r03_pmc_lde.json"
+            with open(os.path.join(root, "profiles", name)) as f:
                 pmc = json.load(f)
             if (self.log_height, self.width, self.log_blowup) == (16, 2633, 1) and "cfg5_lde_2^16x2633_blowup2" in pmc:
                 traffic = pmc["cfg5_lde_2^16x2633_blowup2"]["total_bytes"]
-                src = ("profiles/r03_pmc_lde.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, summed over the "
-                       "unit's launches (tools/pmc_probe.py, tools/pmc_summarize.py).  An UPPER bound: the x2 is calibrated for aligned "
-                       "16-byte-per-lane reads; this plan reads 4 bytes per lane and the rows of a 2633-word matrix are not multiples of 128 "
-                       "bytes: K3's 2.73 GB stands for 1.38 GB of reads either counted or fetched twice (a tile order that gives neighbours in a "
-                       "row to one XCD changed neither the counter nor the time).  The structure moves 6.2 GB = 9 matrix sweeps")
+                src = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE, separate passes, summed over the unit's launches "
+                       "(tools/pmc_probe.py, tools/pmc_summarize.py).  FETCH_SIZE x2 (gfx950) for K1 / K2, x1 for K3: a calibration kernel with "
+                       "K3's access shape (4-byte lanes on 128-byte segments of 10532-byte rows) shows those reads tallied in full "
+                       "(profiles/r04_fetch_calib.json: factor 1.016 against 2.000 for the same access on 128-byte-multiple rows), so round 3's "
+                       "2.73 GB for K3's 1.38 GB input was the correction, not a double fetch.  The structure moves 6.2 GB = 9 matrix sweeps; what "
+                       "is above that is write amplification on rows that are not multiples of 128 bytes" % name)
         except Exception:
             pass
         return {"bound": "hbm", "kernel": "coset_lde_batch of the wide matrix (two-digit plan with 128-byte tile rows: narrow_inv1 / narrow_mid / narrow_fwd2 <8, 5, 1>)",

@@ -913,9 +913,12 @@ int launch_narrow64(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32
 // Narrow-matrix coset LDE in three launches (ntt_narrow.hip.h).  Returns 1 when the shape is not covered.
 // WIDE matrices (more than 16 columns, any width incl. odd ones) on the same two-digit plan: single columns per lane and tiles
 // of 2^8 rows x 32 words, i.e. 128-byte row segments (the slots of a row group are its words in memory order, so a tile may
-// straddle rows).  Instantiated for 8-stage digits: 2^16 rows — BASELINE configs[4], 2^16 x 2633.
+// straddle rows).  Instantiated for 8- and 9-stage digits: 2^16 rows (BASELINE configs[4], 2^16 x 2633), 2^17 and 2^18 rows
+// (a 10-stage digit would need 2048 threads at this tile width).
 template <int K>
-int launch_narrow_wide(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t blocks, uint32_t gy, bool f64) {
+int launch_narrow_wide(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t b, uint32_t blocks, uint32_t gy, bool f64) {
+    if (b == 9) return launch_narrow_t<9, 5, 1, K>(cx, stream, a, blocks, gy);  // 2^17 / 2^18 rows: 1024-thread tiles, integer only
+    if (b != 8) return fail(ERR_INTERNAL, "lde_narrow: wide digit out of range");
     if (f64) return launch_narrow64_t<8, 5, 1, K>(cx, stream, a, blocks, gy);
     return launch_narrow_t<8, 5, 1, K>(cx, stream, a, blocks, gy);
 }
@@ -933,7 +936,7 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     static int wide_on = [] { const char* e = getenv("P3HIP_NTT_NARROW_WIDE"); return e ? atoi(e) : 1; }();
     // 128-byte tile rows, single columns: any width whose byte offsets stay below 2^32 (the kernels index in u32: K1's
     // transposed store reaches rows * W * 4 bytes of the coefficient matrix, K2 / K3 the LDE's (rows << added) * W * 4)
-    const bool wide = W > w_max && wide_on && n == 16 && W >= 64 && (((uint64_t)W << (n + added + 2)) < (1ull << 32));
+    const bool wide = W > w_max && wide_on && n >= 16 && n <= 18 && W >= 64 && (((uint64_t)W << (n + added + 2)) < (1ull << 32));
     if (!wide && (W < 2 || W > w_max || !(is_pow2(W) || W == 6))) return 1;
     if (n < n_min || n < 16 || n > 24) return 1;
     if (!wide && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 7u)) return 1;  // 8-byte accesses
@@ -1006,7 +1009,7 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     static int f64_env = [] { const char* e = getenv("P3HIP_NTT_NARROW_F64"); return e ? atoi(e) : -1; }();
     const int f64_mask = f64_env >= 0 ? f64_env : ((!wide && (n <= 19 || (n == 20 && W == 2))) ? 7 : 0);  // wide: 2143 us integer, 2287 us fp64
     auto f64 = [&](int k, uint32_t b) {
-        if (!((f64_mask >> k) & 1)) return false;
+        if (!((f64_mask >> k) & 1) || (wide && b != 8)) return false;
         return b - 4 + lq_of(k, b) <= (k == 1 ? 9u : 10u);
     };
     // fp64 kernels: hand-overs as doubles, or as words (P3HIP_NTT_NARROW_F64_XW=1; tiles of the integer kernels' size, five more
@@ -1026,7 +1029,7 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     }
 #endif
     if (!from_coeffs)
-        if ((rc = wide ? launch_narrow_wide<1>(cx, stream, a, tiles, 1, f64(0, n1))
+        if ((rc = wide ? launch_narrow_wide<1>(cx, stream, a, n1, tiles, 1, f64(0, n1))
                        : f64(0, n1) ? launch_narrow64<1>(cx, stream, a, n1, tiles, vw[0]) : launch_narrow<1>(cx, stream, a, n1, tiles, vw[0]))) return rc;
 #if NARROW_STAMPS
     if (a.stamps) {
@@ -1068,7 +1071,7 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     if (cos_split < 0) { while (split_log < added && ((uint64_t)tiles << (split_log + 1)) <= 256) split_log++; }
     else split_log = std::min<uint32_t>((uint32_t)cos_split, added);
     a.cos_per_block = (1u << added) >> split_log;
-    if ((rc = wide ? launch_narrow_wide<2>(cx, stream, a, tiles, 1u << split_log, f64(1, n2))
+    if ((rc = wide ? launch_narrow_wide<2>(cx, stream, a, n2, tiles, 1u << split_log, f64(1, n2))
                    : f64(1, n2) ? launch_narrow64<2>(cx, stream, a, n2, tiles, vw[1], 1u << split_log)
                                 : launch_narrow<2>(cx, stream, a, n2, tiles, vw[1], 1u << split_log))) return rc;
     // K3
@@ -1078,7 +1081,7 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     tiles = geometry(2, n1, (1ull << added) << n2);
     a.k3_pairs = k3_out_of_place && vw[2] == 2 && tiles % 16 == 0 ? 1u : 0u;
     if (wide && tiles % 128 == 0) a.k3_pairs = 4;
-    if (wide) return launch_narrow_wide<3>(cx, stream, a, tiles, 1, f64(2, n1));
+    if (wide) return launch_narrow_wide<3>(cx, stream, a, n1, tiles, 1, f64(2, n1));
     if (k3_lq1) return f64(2, n1) ? launch_narrow64_t<10, 1, 2, 3>(cx, stream, a, tiles, 1) : launch_narrow_t<10, 1, 2, 3>(cx, stream, a, tiles, 1);
     return f64(2, n1) ? launch_narrow64<3>(cx, stream, a, n1, tiles, vw[2]) : launch_narrow<3>(cx, stream, a, n1, tiles, vw[2]);
 }

@@ -315,34 +315,42 @@ __global__ void __launch_bounds__(256) rng_compact_kernel(DevRng* st, const uint
     if (base >= n) return;  // the stream was complete before this chunk
     const uint4 v4 = reinterpret_cast<const uint4*>(raw + ((size_t)c << RNG_CHUNK_LOG))[lane];
     const uint32_t v[4] = {v4.x, v4.y, v4.z, v4.w};
-    uint32_t mine = 0;
+    // rank of candidate 4 lane + k among the chunk's accepted ones = accepted candidates of lower lanes (the four acceptance BALLOTS,
+    // counted below this lane by v_mbcnt: eight instructions, no shuffle scan) + accepted ones of this lane before k
+    uint32_t below = 0, total = 0;
+    bool acc[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) mine += v[k] < bb::P ? 1u : 0u;
-    uint32_t inc = mine;  // inclusive scan over the wave
-#pragma unroll
-    for (uint32_t off = 1; off < 64; off <<= 1) {
-        const uint32_t u = (uint32_t)__shfl_up((int)inc, off, 64);
-        if (lane >= off) inc += u;
+    for (int k = 0; k < 4; k++) {
+        acc[k] = v[k] < bb::P;
+        const uint64_t b = __ballot(acc[k]);
+        below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, below));
+        total += (uint32_t)__builtin_popcountll(b);  // wave-uniform: scalar
     }
     // accepted values to their rank in the wave's 256-word LDS row, then out in rank order: lane l writes ranks l, l + 64, ... so
     // every store instruction of the wave covers 256 contiguous bytes
     __shared__ uint32_t packed[4][RNG_CHUNK];
     uint32_t* row = packed[threadIdx.x >> 6];
-    uint32_t rank = inc - mine;
+    uint32_t rank = below;
 #pragma unroll
     for (uint32_t k = 0; k < 4; k++) {
-        if (v[k] < bb::P) {
-            row[rank] = v[k];
-            if (base + rank + 1 == n) {  // the n-th element: replay this chunk up to raw draw 4 lane + k
-                uint64_t s[4] = {states[(size_t)c * 4], states[(size_t)c * 4 + 1], states[(size_t)c * 4 + 2], states[(size_t)c * 4 + 3]};
-                for (uint32_t i = 0; i <= 4 * lane + k; i++) (void)xoshiro_next(s);
+        if (acc[k]) row[rank++] = v[k];
+    }
+    if (n - base <= total) {  // wave-uniform, true for ONE wave of the fill: the n-th element lies in this chunk
+        const uint32_t want = (uint32_t)(n - base) - 1u;  // its rank
+        uint32_t r = below;
 #pragma unroll
-                for (int w = 0; w < 4; w++) st->s[w] = s[w];
+        for (uint32_t k = 0; k < 4; k++) {
+            if (acc[k]) {
+                if (r == want) {  // replay this chunk up to raw draw 4 lane + k: the stream continues right after it
+                    uint64_t s[4] = {states[(size_t)c * 4], states[(size_t)c * 4 + 1], states[(size_t)c * 4 + 2], states[(size_t)c * 4 + 3]};
+                    for (uint32_t i = 0; i <= 4 * lane + k; i++) (void)xoshiro_next(s);
+#pragma unroll
+                    for (int w = 0; w < 4; w++) st->s[w] = s[w];
+                }
+                r++;
             }
-            rank++;
         }
     }
-    const uint32_t total = (uint32_t)__shfl((int)inc, 63, 64);
     __builtin_amdgcn_wave_barrier();  // the row belongs to this wave alone: LDS operations of one wave complete in order
 #pragma unroll
     for (uint32_t i = 0; i < RNG_CHUNK; i += 64) {

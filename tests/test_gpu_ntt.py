@@ -272,12 +272,14 @@ def test_coset_lde_from_coefficients(oracle, p3, log_h, w, ab):
     assert np.array_equal(got, exp)
 
 
-@pytest.mark.parametrize("w,ab", [(64, 1), (65, 2), (100, 1), (333, 1), (257, 3)])
-def test_wide_matrices_on_the_two_digit_plan(dft, oracle, p3, w, ab):
-    """2^16 rows x >= 64 columns (any width, odd ones too): the three-launch plan with 128-byte tile rows, whose tiles straddle
-    matrix rows — the shape class of BASELINE configs[4] (2^16 x 2633, tests/test_gpu_cfg5.py holds that size itself)."""
-    rng = np.random.default_rng(16000 + 10 * w + ab)
-    x = _rand(rng, 1 << 16, w)
+@pytest.mark.parametrize("log_h,w,ab", [(16, 64, 1), (16, 65, 2), (16, 100, 1), (16, 333, 1), (16, 257, 3),
+                                        (17, 65, 1), (17, 100, 2), (18, 77, 1), (18, 64, 2)])
+def test_wide_matrices_on_the_two_digit_plan(dft, oracle, p3, log_h, w, ab):
+    """2^16..2^18 rows x >= 64 columns (any width, odd ones too): the three-launch plan with 128-byte tile rows, whose tiles straddle
+    matrix rows — the shape class of BASELINE configs[4] (2^16 x 2633, tests/test_gpu_cfg5.py holds that size itself).  2^17 and
+    2^18 rows run 9-stage digits on 1024-thread tiles (round 4)."""
+    rng = np.random.default_rng(1000 * log_h + 10 * w + ab)
+    x = _rand(rng, 1 << log_h, w)
     shift = p3.GENERATOR_MONTY if w % 2 == 0 else int(rng.integers(1, P))
     assert np.array_equal(dft.coset_lde_batch(x, ab, shift, bit_reversed_out=True), oracle.coset_lde_batch(x, ab, shift, True))
 

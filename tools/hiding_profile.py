@@ -10,7 +10,9 @@ from __graft_entry__ import load_package  # noqa: E402
 p3 = load_package()
 hash = sys.argv[1] if len(sys.argv) > 1 else "poseidon2"
 log_n = int(sys.argv[2]) if len(sys.argv) > 2 else 19
-pr = p3.FibAirProver(log_n, params=p3.FriParameters(), hash=hash, hiding=True)
+# log_n = 3 is the reference's own instance: create_test_fri_params(challenge_mmcs, 2) (fib_air.rs:62)
+params = p3.FriParameters(2, 2, 2, 1) if log_n == 3 else p3.FriParameters()
+pr = p3.FibAirProver(log_n, params=params, hash=hash, hiding=True)
 for i in range(6):
     pr.prove(i, i + 1)
 pr.close()

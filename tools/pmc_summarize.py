@@ -23,7 +23,17 @@ def read(dirname, counter):
 
 fetch, write = read(sys.argv[1], "FETCH_SIZE"), read(sys.argv[2], "WRITE_SIZE")
 assert [k for _, k, _ in fetch] == [k for _, k, _ in write], "the two passes must run the same launches"
-launches = [{"kernel": k[:60], "fetch_bytes": 2.0 * f * 1024, "write_bytes": w * 1024}
+
+
+# FETCH_SIZE factor per kernel: 2 (aligned 128-byte requests tallied at 64 bytes) unless a calibration with a known byte count in
+# the kernel's own access shape says otherwise.  tools/fetch_calib.hip (profiles/r04_fetch_calib.json): 4-byte lanes on 128-byte
+# segments of rows that are NOT multiples of 128 bytes — K3 of the wide plan on a 2633-word-row matrix — are tallied in full
+# (factor 1.016); the same access on 128-byte-multiple rows, and 16-byte lanes, are halved (factor 2.000).
+def fetch_factor(kernel):
+    return 1.0 if kernel.startswith("void p3::narrow_fwd2_kernel<8, 5, 1>") or kernel.startswith("void p3::narrow_fwd2_kernel<9, 5, 1>") else 2.0
+
+
+launches = [{"kernel": k[:60], "fetch_bytes": fetch_factor(k) * f * 1024, "write_bytes": w * 1024, "fetch_factor": fetch_factor(k)}
             for (_, k, f), (_, _, w) in zip(fetch, write)]
 
 
@@ -43,7 +53,8 @@ def first(prefix):
 out = {
     "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE runs of tools/pmc_probe.py; "
               "counters are KiB; FETCH_SIZE doubled (gfx950 reports 1/2 of streamed read bytes, MI355X_MICROARCH.md HBM "
-              "section); summarised by tools/pmc_summarize.py",
+              "section) EXCEPT for the wide plan's K3 on rows that are not multiples of 128 bytes, whose reads a calibration kernel of "
+              "the same access shape shows tallied in full (profiles/r04_fetch_calib.json); summarised by tools/pmc_summarize.py",
     "calibration_bytes": {
         "fib_trace 2^24 rows (writes 128 MiB)": first("fib_trace_kernel"),
         "poseidon2 permute 2^22 states in place (reads 256 MiB, writes 256 MiB)": first("poseidon2_permute"),

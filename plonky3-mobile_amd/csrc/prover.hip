@@ -102,11 +102,11 @@ __global__ void __launch_bounds__(256) fib_quotient_kernel(QuotArgs a) {
     uint32_t c2 = bb::mul(trans, bb::sub(loc.y, nxt.x));
     uint32_t c3 = bb::mul(trans, bb::sub(bb::add(loc.x, loc.y), nxt.y));
     uint32_t c4 = bb::mul(s.y, bb::sub(loc.y, ds->pis[2]));
-    Ext acc = bb::scale(ds->apow[4], c0);
-    acc = bb::add(acc, bb::scale(ds->apow[3], c1));
-    acc = bb::add(acc, bb::scale(ds->apow[2], c2));
-    acc = bb::add(acc, bb::scale(ds->apow[1], c3));
-    acc = bb::add(acc, bb::scale(ds->apow[0], c4));
+    Ext acc;
+#pragma unroll
+    for (int k = 0; k < 4; k++)  // five products per coefficient: two dot2 and one product
+        acc.c[k] = bb::add(bb::add(bb::dot2(ds->apow[4].c[k], c0, ds->apow[3].c[k], c1), bb::dot2(ds->apow[2].c[k], c2, ds->apow[1].c[k], c3)),
+                           bb::mul(ds->apow[0].c[k], c4));
     st_ext(a.out + 4 * (size_t)i, bb::scale(acc, a.zh_inv));
 }
 
@@ -177,20 +177,29 @@ __global__ void __launch_bounds__(BARY_BLOCK) barycentric_kernel(TwoLevelTable r
     Ext acc[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) acc[k] = bb::ext_zero();
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-        uint32_t x = bb::mul(gen, tl(roots, brev(j, log_big)));
-        Ext e0 = bb::scale(ld_ext(d0 + 4 * (size_t)j), x);
-        Ext e1 = bb::scale(ld_ext(d1 + 4 * (size_t)j), x);
-        uint2 t = lde_t[j];
-        uint4 q = lde_q[j];
-        acc[0] = bb::add(acc[0], bb::scale(e0, t.x));
-        acc[1] = bb::add(acc[1], bb::scale(e0, t.y));
-        acc[2] = bb::add(acc[2], bb::scale(e1, t.x));
-        acc[3] = bb::add(acc[3], bb::scale(e1, t.y));
-        acc[4] = bb::add(acc[4], bb::scale(e0, q.x));
-        acc[5] = bb::add(acc[5], bb::scale(e0, q.y));
-        acc[6] = bb::add(acc[6], bb::scale(e0, q.z));
-        acc[7] = bb::add(acc[7], bb::scale(e0, q.w));
+    // two rows per step: acc += e_j v_j + e_j' v_j' under ONE Montgomery reduction per coefficient (bb::dot2); a lane whose second
+    // row lies past the end pairs its row with a zero weight
+    const uint32_t step = gridDim.x * blockDim.x;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += 2 * step) {
+        const bool two = j + step < n;
+        const uint32_t j2 = two ? j + step : j;
+        const uint32_t xa = bb::mul(gen, tl(roots, brev(j, log_big))), xb = two ? bb::mul(gen, tl(roots, brev(j2, log_big))) : 0u;
+        const Ext e0a = bb::scale(ld_ext(d0 + 4 * (size_t)j), xa), e1a = bb::scale(ld_ext(d1 + 4 * (size_t)j), xa);
+        const Ext e0b = bb::scale(ld_ext(d0 + 4 * (size_t)j2), xb), e1b = bb::scale(ld_ext(d1 + 4 * (size_t)j2), xb);
+        const uint2 ta = lde_t[j], tb = lde_t[j2];
+        const uint4 qa = lde_q[j], qb = lde_q[j2];
+        auto fma2 = [](Ext& s, const Ext& ea, uint32_t va, const Ext& eb, uint32_t vb) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) s.c[c] = bb::add(s.c[c], bb::dot2(ea.c[c], va, eb.c[c], vb));
+        };
+        fma2(acc[0], e0a, ta.x, e0b, tb.x);
+        fma2(acc[1], e0a, ta.y, e0b, tb.y);
+        fma2(acc[2], e1a, ta.x, e1b, tb.x);
+        fma2(acc[3], e1a, ta.y, e1b, tb.y);
+        fma2(acc[4], e0a, qa.x, e0b, qb.x);
+        fma2(acc[5], e0a, qa.y, e0b, qb.y);
+        fma2(acc[6], e0a, qa.z, e0b, qb.z);
+        fma2(acc[7], e0a, qa.w, e0b, qb.w);
     }
     __shared__ uint32_t red[BARY_BLOCK / 64][32];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -232,13 +241,16 @@ __global__ void __launch_bounds__(256) reduced_openings_kernel(ReducedArgs a) {
     const DevState* __restrict__ ds = a.ds;
     uint2 t = a.lde_t[j];
     uint4 q = a.lde_q[j];
-    Ext u = bb::scale(ds->alp[1], t.y);  // rt
+    // u = t.x + alp1 t.y + alp4 q.x + alp5 q.y + alp6 q.z + alp7 q.w, w = alp2 t.x + alp3 t.y: extension-by-base products summed two per
+    // Montgomery reduction (bb::dot2: 6 instructions for two terms instead of 2 x 5 + 3)
+    Ext u, w;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        u.c[c] = bb::add(bb::add(bb::dot2(ds->alp[4].c[c], q.x, ds->alp[5].c[c], q.y), bb::dot2(ds->alp[6].c[c], q.z, ds->alp[7].c[c], q.w)),
+                         bb::mul(ds->alp[1].c[c], t.y));
+        w.c[c] = bb::dot2(ds->alp[2].c[c], t.x, ds->alp[3].c[c], t.y);
+    }
     u.c[0] = bb::add(u.c[0], t.x);
-    u = bb::add(u, bb::scale(ds->alp[4], q.x));
-    u = bb::add(u, bb::scale(ds->alp[5], q.y));
-    u = bb::add(u, bb::scale(ds->alp[6], q.z));
-    u = bb::add(u, bb::scale(ds->alp[7], q.w));
-    Ext w = bb::add(bb::scale(ds->alp[2], t.x), bb::scale(ds->alp[3], t.y));  // alpha^2 rt
     Ext e0 = ld_ext(a.d0 + 4 * (size_t)j), e1 = ld_ext(a.d1 + 4 * (size_t)j);
     Ext r = bb::add(bb::mul(bb::sub(ds->y02, u), e0), bb::mul(bb::sub(ds->y1, w), e1));
     st_ext(a.ro + 4 * (size_t)j, r);

@@ -360,14 +360,83 @@ __global__ void __launch_bounds__(256) rng_compact_kernel(DevRng* st, const uint
     if (c + 1 == n_chunks && lane == 0 && base + total < n) atomicOr(err, 1u);  // ran out of raw draws (never, with the margin used)
 }
 
-__global__ void rng_set_kernel(DevRng* st, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
-    st->s[0] = a; st->s[1] = b; st->s[2] = c; st->s[3] = d;
+// SMALL fills (up to 32 chunks = 8192 raw draws) in ONE launch of one wave: the reference's own instance (n = 8, fib_air.rs:56-57)
+// draws 304, 1536 and ~200 elements per stream, and the four-launch path above costs such a fill ~50 us whatever its size (two waves
+// walking 63 jump products each for chunks nobody needs, two scan launches over a few counters).  Lane l walks to chunk l (only the
+// chunks the fill can need), generates its 256 candidates into LDS, the wave scans the 32 counts in registers and compacts chunk by
+// chunk with ballot ranks; the lane that owns the chunk of the n-th element replays it and leaves the generator state.
+constexpr uint32_t RNG_SMALL_CHUNKS = 32, RNG_SMALL_STRIDE = RNG_CHUNK + 1;
+__global__ void __launch_bounds__(64) rng_small_fill_kernel(DevRng* st, const uint64_t* __restrict__ jump, uint32_t n_chunks, uint32_t* out, uint32_t n,
+                                                            uint32_t* err) {
+    __shared__ uint32_t raw[RNG_SMALL_CHUNKS * RNG_SMALL_STRIDE];
+    const uint32_t lane = threadIdx.x;
+    uint64_t cur[4] = {st->s[0], st->s[1], st->s[2], st->s[3]};
+    to_interleaved(cur);
+    const LaneRows j0 = load_rows(jump);
+    uint64_t s[4] = {cur[0], cur[1], cur[2], cur[3]};
+    for (uint32_t i = 1; i < n_chunks; i++) {
+        wave_matvec(j0, cur);
+        if (lane == i) { s[0] = cur[0]; s[1] = cur[1]; s[2] = cur[2]; s[3] = cur[3]; }
+    }
+    from_interleaved(s);
+    const uint64_t s_start[4] = {s[0], s[1], s[2], s[3]};
+    uint32_t cnt = 0;
+    if (lane < n_chunks) {
+        for (uint32_t i = 0; i < RNG_CHUNK; i++) {
+            const uint32_t v = (uint32_t)(xoshiro_next(s) >> 32) >> 1;
+            cnt += v < bb::P ? 1u : 0u;
+            raw[lane * RNG_SMALL_STRIDE + i] = v;
+        }
+    }
+    uint32_t inc = cnt;  // inclusive scan of the chunk counts over the wave
+#pragma unroll
+    for (uint32_t off = 1; off < 64; off <<= 1) {
+        const uint32_t u = (uint32_t)__shfl_up((int)inc, off, 64);
+        if (lane >= off) inc += u;
+    }
+    const uint32_t my_base = inc - cnt;
+    __syncthreads();  // one wave: orders the LDS writes before the reads below
+    for (uint32_t c = 0; c < n_chunks; c++) {  // wave-uniform
+        const uint32_t base = (uint32_t)__shfl((int)my_base, (int)c, 64);
+        if (base >= n) break;
+        uint32_t v[4], below = 0;
+        bool acc[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            v[k] = raw[c * RNG_SMALL_STRIDE + 4 * lane + k];
+            acc[k] = v[k] < bb::P;
+            const uint64_t b = __ballot(acc[k]);
+            below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, below));
+        }
+        uint32_t rank = base + below;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (acc[k]) { if (rank < n) out[rank] = v[k]; rank++; }
+    }
+    // generator state right after the n-th accepted draw: the lane whose chunk holds it replays that chunk
+    const uint32_t total = (uint32_t)__shfl((int)inc, 63, 64);
+    if (total < n) { if (lane == 0) atomicOr(err, 1u); return; }  // ran out of raw draws (never, with the margin used)
+    if (lane < n_chunks && my_base < n && n <= my_base + cnt) {
+        uint64_t r[4] = {s_start[0], s_start[1], s_start[2], s_start[3]};
+        uint32_t need = n - my_base;  // accepted draws of this chunk up to and including the n-th element
+        while (need) {
+            const uint32_t v = (uint32_t)(xoshiro_next(r) >> 32) >> 1;
+            need -= v < bb::P ? 1u : 0u;
+        }
+#pragma unroll
+        for (int w = 0; w < 4; w++) st->s[w] = r[w];
+    }
 }
 
-int rng_seed(hipStream_t stream, DevRng* st, uint64_t seed) {
+__global__ void rng_set_kernel(DevRng* st, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
+    DevRng* r = st + threadIdx.x;  // `count` consecutive streams, all seeded alike (the hiding prover's three: one launch)
+    r->s[0] = a; r->s[1] = b; r->s[2] = c; r->s[3] = d;
+}
+
+int rng_seed(hipStream_t stream, DevRng* st, uint64_t seed, uint32_t count) {
     uint64_t s[4];
     rng_seed_from_u64(s, seed);
-    hipLaunchKernelGGL(rng_set_kernel, dim3(1), dim3(1), 0, stream, st, s[0], s[1], s[2], s[3]);
+    hipLaunchKernelGGL(rng_set_kernel, dim3(1), dim3(count), 0, stream, st, s[0], s[1], s[2], s[3]);
     P3_HIP(hipGetLastError());
     return OK;
 }
@@ -394,6 +463,17 @@ int rng_fill_field(Context& cx, hipStream_t stream, DevRng* st, uint32_t* out, u
         P3_HIP(hipMemcpy(cx.rng_jump, j.data(), j.size() * 8, hipMemcpyHostToDevice));
     }
     // raw draws: n / (P / 2^31) = n * 1.0667 expected; 12.5 % + 64 chunks of margin is > 50 standard deviations
+    {   // small fills: one launch (rng_small_fill_kernel).  Margin: n / 8 + 1024 raw draws beyond n is > 50 standard deviations of the
+        // rejections for every n (expected n / 15, deviation 0.27 sqrt(n)); P3HIP_RNG_SMALL=0 keeps the general path
+        static const bool small_on = [] { const char* e = getenv("P3HIP_RNG_SMALL"); return !e || atoi(e) != 0; }();
+        const uint64_t raw_small = n + n / 8 + 1024;
+        const uint64_t chunks_small = (raw_small + RNG_CHUNK - 1) / RNG_CHUNK;
+        if (small_on && chunks_small <= RNG_SMALL_CHUNKS) {
+            hipLaunchKernelGGL(rng_small_fill_kernel, dim3(1), dim3(64), 0, stream, st, cx.rng_jump, (uint32_t)chunks_small, out, (uint32_t)n, err);
+            P3_HIP(hipGetLastError());
+            return OK;
+        }
+    }
     const uint64_t raw = n + n / 8 + 64 * (uint64_t)RNG_CHUNK;
     const uint64_t chunks64 = (raw + RNG_CHUNK - 1) / RNG_CHUNK;
     if (chunks64 >> RNG_MAX_JUMP) return fail(ERR_BAD_ARG, "rng: fill too large");

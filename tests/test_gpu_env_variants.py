@@ -26,6 +26,11 @@ VARIANTS = [
     {"P3HIP_RNG_TWO_PASS": "1", "P3HIP_LEAF_WIDE": "0", "P3HIP_HIDING_BARY_SPLIT": "1"},                    # first forms of the RNG fill and of the wide-row leaf kernel
     {"P3HIP_NTT_NARROW_BLOCKED12": "0", "P3HIP_NTT_NARROW_K3_LQ1": "1", "P3HIP_NTT_NARROW_WIDE": "0", "P3HIP_VARIANT_BIG_LDE": "1"},
     {"P3HIP_NTT_NARROW_BLOCKED12": "0", "P3HIP_VARIANT_CFG3_LDE": "1"},   # cfg3's LDE shape on the row-major intermediates
+    # round 4's switches: generic row-set leaf kernel for the salted leaves, four-launch RNG fill for small fills too, fills on the
+    # prover's own stream; RNG generation with four / two chunks per lane at sizes whose waves are then only partly filled
+    {"P3HIP_LEAF_SALTED": "0", "P3HIP_RNG_SMALL": "0", "P3HIP_HIDING_RNG_SIDE": "0"},
+    {"P3HIP_RNG_SUB_LOG": "2", "P3HIP_RNG_SMALL": "0"},
+    {"P3HIP_RNG_SUB_LOG": "1", "P3HIP_RNG_SMALL": "0"},
 ]
 
 

@@ -48,4 +48,12 @@ for log_h, w, ab in shapes:
 hp = p3.FibAirProver(9, params=p3.FriParameters(1, 0, 8, 4), hash="keccak", hiding=True, seed=1)
 assert hp.prove(0, 1) == o.prove_fib_air_hiding(0, 1, 9, o.FriParams(1, 0, 8, 4), hash=o.HASH_KECCAK, seed=1)
 hp.close()
+# the device SmallRng stream in whichever form the environment selects (chunks per lane, small-fill kernel or not), across sizes that
+# leave the last wave of a fill partly filled
+dr, host = p3.DeviceRng(1), o.rng_seed_from_u64(1)
+for n in (5, 700, 6371, 6372, 40000, 300001):
+    got = p3.host_u32(dr.fill_field(n))
+    assert np.array_equal(got, o.rng_fill_field(host, n)), ("rng", n)
+    assert dr.state() == list(host), ("rng state", n)
+dr.close()
 print("variant ok")

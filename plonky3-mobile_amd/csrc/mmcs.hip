@@ -14,6 +14,7 @@
 #include "poseidon2.hip.h"
 #include "poseidon2_coop.hip.h"
 #include "poseidon2_f64.hip.h"
+#include "poseidon2_q4.hip.h"
 #include "keccak.hip.h"
 
 namespace p3 {
@@ -155,6 +156,55 @@ __global__ void __launch_bounds__(256) leaf_hash_f64_kernel(const uint32_t* mat,
 #pragma unroll
     for (int i = 0; i < 8; i++) d[i] = p2f::store_elem(s[i], smk);
     store_digest(digests + r * 8, d);
+}
+// ---- one state per DPP quad (poseidon2_q4.hip.h): the layers of 2^12 .. 2^15 digests, whose one-state-per-lane launches cost one
+// permutation's issue time (11.5-12.4 us) whatever their size.  Lane q of a quad holds state elements 4q .. 4q+3: a child pair's
+// sixteen words are four 16-byte loads of one quad, the digest is two 16-byte stores.
+__global__ void __launch_bounds__(256) compress_layer_q4_kernel(const uint32_t* prev, uint32_t* next, uint64_t n_out, uint32_t prio) {
+    if (prio) P3_LATENCY_BOUND_KERNEL();
+    const uint32_t q = threadIdx.x & 3u;
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const bool act = i < n_out;  // idle quads run the permutation on zeros: every lane of a wave takes part in the exchanges
+    const p2q::LaneConsts lc = p2q::lane_consts(q);
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    if (act) {
+        const uint4 w = *reinterpret_cast<const uint4*>(prev + i * 16 + 4 * q);
+        s[0] = p2f::load_elem(w.x); s[1] = p2f::load_elem(w.y); s[2] = p2f::load_elem(w.z); s[3] = p2f::load_elem(w.w);
+    }
+    p2q::permute(s, lc, q == 0);
+    if (act && q < 2) {
+        const p2f::MagicRegs smk = p2f::magic_regs();
+        *reinterpret_cast<uint4*>(next + i * 8 + 4 * q) =
+            make_uint4(p2f::store_elem(s[0], smk), p2f::store_elem(s[1], smk), p2f::store_elem(s[2], smk), p2f::store_elem(s[3], smk));
+    }
+}
+// the sponge over the rows of ONE dense matrix, one row per quad: lanes 0 and 1 of the quad overwrite their elements with the next
+// eight words of the row (overwrite-mode absorb), every lane permutes
+__global__ void __launch_bounds__(256) leaf_hash_q4_kernel(const uint32_t* mat, uint32_t width, uint64_t n_rows, uint32_t* digests, uint32_t prio) {
+    if (prio) P3_LATENCY_BOUND_KERNEL();
+    const uint32_t q = threadIdx.x & 3u;
+    const uint64_t r = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const bool act = r < n_rows;
+    const p2q::LaneConsts lc = p2q::lane_consts(q);
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    const uint32_t* row = mat + (act ? r : 0) * width;
+    for (uint32_t k = 0; k < width; k += 8) {
+        if (act && q < 2) {
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++)
+                if (k + 4 * q + i < width) s[i] = p2f::load_elem(row[k + 4 * q + i]);
+        }
+        p2q::permute(s, lc, q == 0);
+        if (k + 8 < width) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) s[i] = p2f::reduce(s[i]);  // keep magnitudes small between absorptions
+        }
+    }
+    if (act && q < 2) {
+        const p2f::MagicRegs smk = p2f::magic_regs();
+        *reinterpret_cast<uint4*>(digests + r * 8 + 4 * q) =
+            make_uint4(p2f::store_elem(s[0], smk), p2f::store_elem(s[1], smk), p2f::store_elem(s[2], smk), p2f::store_elem(s[3], smk));
+    }
 }
 // WIDE rows (BASELINE configs[4]: 2633 words per row): in the kernel above a lane walks its own row, so every load instruction of a
 // wave touches 64 lines 10 KB apart.  Here the workgroup's 256 rows are staged through LDS in chunks of 32 words per row, loaded
@@ -814,6 +864,13 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
     // digests per workgroup of the 16-lane cooperative Poseidon2 levels kernel: 2^5 = four waves, five levels per launch (2^7, sixteen
     // waves on one CU and seven levels, measured 1.5 % slower at four provers)
     static const uint32_t COOP_CHUNK_LOG = [] { const char* e = getenv("P3HIP_COOP_CHUNK_LOG"); int v = e ? atoi(e) : 5; return (uint32_t)(v < 3 ? 3 : (v > 7 ? 7 : v)); }();
+    // One state per quad (poseidon2_q4.hip.h) for layers of COOP_MAX .. 2^P3HIP_Q4_MAX_LOG permutations: 4-7 us a launch instead of ~12 at
+    // 1.6x the lane-instructions.  A LATENCY switch, off by default: a single 2^20 proof 3.53 -> 3.33-3.38 ms with 15, but four concurrent
+    // provers LOSE 3.8 % (587 -> 565 proofs/s; 13: 565, 14: 560; without the raised wave priority: 490) — the extra lane-instructions
+    // run at priority 3 against the other provers' hash layers (profiles/r04_latency_ab.txt).  At 2^16 permutations the quad form would
+    // be four waves per SIMD and loses to the per-lane form's one even alone.
+    static const uint64_t Q4_MAX = [] { const char* e = getenv("P3HIP_Q4_MAX_LOG"); int v = e ? atoi(e) : 0; return v <= 0 ? (uint64_t)0 : (uint64_t)1 << (v > 17 ? 17 : v); }();
+    static const uint32_t Q4_PRIO = [] { const char* e = getenv("P3HIP_Q4_PRIO"); return (uint32_t)(e ? atoi(e) : 1); }();
     // Cooperative Keccak levels for layers of <= 2^10 digests: one state per wave spends ~13x the lane-instructions of the per-lane form,
     // and with four provers VALU is what the chip is short of (2^12: 624.6 proofs/s, 2^11: 633, 2^10: 647, 2^9: 636 in the Keccak bench;
     // the hiding bench does not care; a single proof's latency prefers 12: +0.2 ms at 10)
@@ -870,6 +927,9 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
         if (dense1 && maxh < COOP_MAX && maxh * 16 <= 0x7fffffffull) {
             hipLaunchKernelGGL(leaf_coop_kernel, dim3((uint32_t)((maxh * 16 + 255) / 256)), dim3(256), 0, stream, rs.ptr[0],
                                rs.width[0], (uint32_t)maxh, t->layers);
+        } else if (dense1 && use_f64_tree() && maxh <= Q4_MAX && rs.width[0] <= 64 && (reinterpret_cast<uintptr_t>(t->layers) & 15u) == 0) {
+            hipLaunchKernelGGL(leaf_hash_q4_kernel, dim3((uint32_t)((maxh * 4 + 255) / 256)), dim3(256), 0, stream, rs.ptr[0], rs.width[0], maxh,
+                               t->layers, Q4_PRIO);
         } else if (dense1 && use_f64_tree() && rs.width[0] >= 64 && leaf_wide_enabled()) {
             hipLaunchKernelGGL(leaf_hash_f64_wide_kernel, dim3((uint32_t)((maxh + 255) / 256)), dim3(256), 0, stream, rs.ptr[0],
                                rs.width[0], maxh, t->layers);
@@ -904,7 +964,10 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
             l += levels;
             continue;
         }
-        if (!inject && use_f64_tree()) {
+        if (!inject && use_f64_tree() && len <= Q4_MAX) {
+            hipLaunchKernelGGL(compress_layer_q4_kernel, dim3((uint32_t)((len * 4 + 255) / 256)), dim3(256), 0, stream,
+                               t->layers + t->layer_off[l - 1], t->layers + t->layer_off[l], len, Q4_PRIO);
+        } else if (!inject && use_f64_tree()) {
             hipLaunchKernelGGL(compress_layer_f64_kernel, dim3((uint32_t)((len + 255) / 256)), dim3(256), 0, stream,
                                t->layers + t->layer_off[l - 1], t->layers + t->layer_off[l], len);
         } else {

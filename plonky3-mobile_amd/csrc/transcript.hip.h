@@ -54,7 +54,7 @@ constexpr uint32_t ST_GRIND_MISS = 1u;  // the first search range held no witnes
 struct KState {
     uint64_t st[25];
     uint32_t blen, n_obuf;
-    uint8_t blk[136];
+    alignas(8) uint8_t blk[136];  // word-aligned: k_observe_word stores 32 bits at a time
     uint8_t obuf[32];
 };
 static_assert(sizeof(KState) % 8 == 0, "KState is copied as 64-bit words");
@@ -106,6 +106,20 @@ __device__ __forceinline__ void k_observe_byte(KState* k, uint8_t b) {
     if ((threadIdx.x & 63u) == 0) { k->n_obuf = 0; k->blk[bl] = b; k->blen = bl + 1; }
     lds_wave_sync();
     if (bl + 1 == 136) k_absorb_block(k);
+}
+// A field element's four bytes (little endian) in ONE step: every observation of these transcripts is a 32-bit word and the
+// sponge's fill level starts at 0 or 32 (the chained digest), so the level is always a multiple of four and a word never straddles
+// the 136-byte block.  (The byte-wise form costs an LDS round trip and a wave fence per BYTE: the 576 bytes of the hiding prover's 36
+// opened values were 60 of ts_open_h_kernel's 88 us.)
+__device__ __forceinline__ void k_observe_word(KState* k, uint32_t v) {
+    const uint32_t bl = k->blen;  // the same word for every lane
+    if (bl & 3u) {  // never with these transcripts; kept exact for any other caller
+        for (int i = 0; i < 4; i++) k_observe_byte(k, (uint8_t)(v >> (8 * i)));
+        return;
+    }
+    if ((threadIdx.x & 63u) == 0) { k->n_obuf = 0; *reinterpret_cast<uint32_t*>(k->blk + bl) = v; k->blen = bl + 4; }
+    lds_wave_sync();
+    if (bl + 4 == 136) k_absorb_block(k);
 }
 __device__ __noinline__ void k_flush(KState* k) {  // output = Keccak256(input); the digest also starts the next input
     const uint32_t lane = threadIdx.x & 63u, n = k->blen;
@@ -192,7 +206,7 @@ struct DevChal {
     // ---- the challenger interface: every lane of the wave calls these with the same arguments ----
     __device__ __forceinline__ void observe(uint32_t v) {  // a field element (Montgomery word)
         if (kind == HASH_KECCAK) {
-            for (int i = 0; i < 4; i++) k_observe_byte(k, (uint8_t)(v >> (8 * i)));
+            k_observe_word(k, v);
             return;
         }
         n_out = 0;

@@ -10,7 +10,7 @@ struct DevRng {
 
 void rng_seed_from_u64(uint64_t s[4], uint64_t seed);  // SmallRng::seed_from_u64 (SplitMix64 expansion), host side
 // enqueue: st[0..count) = SmallRng::seed_from_u64(seed)
-int rng_seed(hipStream_t stream, DevRng* st, uint64_t seed, uint32_t count = 1);  // count consecutive streams, the same seed
+int rng_seed(hipStream_t stream, DevRng* st, uint64_t seed, uint32_t count = 1, uint32_t* clear = nullptr);  // count consecutive streams, the same seed; *clear = 0
 // workspace (32-bit words, 8-byte aligned) a fill of up to n_max elements needs
 int rng_workspace_words(uint64_t n_max, size_t* words);
 // whether ONE fill may produce n elements (the jump matrices cover 2^22 chunks of 256 raw draws)

@@ -428,15 +428,16 @@ __global__ void __launch_bounds__(64) rng_small_fill_kernel(DevRng* st, const ui
     }
 }
 
-__global__ void rng_set_kernel(DevRng* st, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
+__global__ void rng_set_kernel(DevRng* st, uint64_t a, uint64_t b, uint64_t c, uint64_t d, uint32_t* clear) {
     DevRng* r = st + threadIdx.x;  // `count` consecutive streams, all seeded alike (the hiding prover's three: one launch)
     r->s[0] = a; r->s[1] = b; r->s[2] = c; r->s[3] = d;
+    if (clear && threadIdx.x == 0) *clear = 0;  // the caller's shortage flag, reset with the streams
 }
 
-int rng_seed(hipStream_t stream, DevRng* st, uint64_t seed, uint32_t count) {
+int rng_seed(hipStream_t stream, DevRng* st, uint64_t seed, uint32_t count, uint32_t* clear) {
     uint64_t s[4];
     rng_seed_from_u64(s, seed);
-    hipLaunchKernelGGL(rng_set_kernel, dim3(1), dim3(count), 0, stream, st, s[0], s[1], s[2], s[3]);
+    hipLaunchKernelGGL(rng_set_kernel, dim3(1), dim3(count), 0, stream, st, s[0], s[1], s[2], s[3], clear);
     P3_HIP(hipGetLastError());
     return OK;
 }

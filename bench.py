@@ -135,7 +135,7 @@ def other_workloads(budget_s=240.0, child_timeout_s=120.0):
     are recorded as skipped.  A child that fails leaves its error text; the main line does not depend on them."""
     import subprocess
     runs = [("cfg2 under the reference's Keccak hashes", ["--hash", "keccak", "--steps", "6", "--warmup", "1"]),
-            ("the reference's own configuration (Keccak + hiding), 2^20 rows", ["--hash", "keccak", "--hiding", "--steps", "3", "--warmup", "1"]),
+            ("the reference's own configuration (Keccak + hiding), 2^20 rows", ["--hash", "keccak", "--hiding", "--steps", "6", "--warmup", "2"]),
             ("cfg3", ["--workload", "cfg3", "--steps", "2", "--warmup", "1"]),
             ("cfg5", ["--workload", "cfg5", "--steps", "6", "--warmup", "2"])]
     res = []

@@ -1,8 +1,8 @@
 // BabyBear (P = 2^31 - 2^27 + 1) Montgomery arithmetic for gfx950 device code and the C++ host side.
 // Same residue system as the reference's shaders (native/shaders/fft_stage.wgsl:36-70,
 // native/src/backend_vulkan.rs:882-917): u32 words x*2^32 mod P kept in [0, P).
-// The reduction is re-derived for CDNA4: three integer multiplies (v_mul_lo/v_mul_hi/v_mul_lo ... )
-// and branch-free min() corrections instead of the reference's compare-and-branch.
+// The reduction is re-derived for CDNA4: two v_mad_u64_u32 and one v_mul_lo_u32 (see mul below) and branch-free
+// min() corrections instead of the reference's compare-and-branch.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -1,7 +1,7 @@
 // The three-launch narrow coset LDE of ntt_narrow.hip.h with its butterflies in DOUBLE PRECISION integer arithmetic.
 //
-// Why it was built: the integer kernels spend 12 VALU instructions per butterfly (add/sub/min, sub/add, and the seven-op Montgomery
-// product).  BabyBear has one spare bit in a 32-bit word (4P > 2^32), so neither Harvey's lazy butterflies nor a signed lazy
+// Why it was built: the integer kernels spent 12 VALU instructions per butterfly (add/sub/min, sub/add, and the then seven-op Montgomery
+// product; ten with the five-instruction product of round 4, bb31.hip.h).  BabyBear has one spare bit in a 32-bit word (4P > 2^32), so neither Harvey's lazy butterflies nor a signed lazy
 // representation fit; in fp64 they do: a lane keeps integers |v| < 2^44 congruent to the Montgomery WORDS (the transform is linear, so
 // the words themselves are transformed, with CANONICAL twiddles), a modular add / sub is ONE v_add_f64 with no reduction for a whole
 // 12-stage digit, and the product is the four-op magic-number form of poseidon2_f64.hip.h:

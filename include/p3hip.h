@@ -104,6 +104,12 @@ int p3hip_coset_lde_batch_bb31_dev(const uint32_t *d_in, uint32_t *d_out, size_t
  * to the subgroup and back (HidingFriPcs commits its blinded quotient chunks from coefficients, fib_air.rs:64-65). */
 int p3hip_coset_lde_from_coeffs_bb31_dev(const uint32_t *d_coeffs, uint32_t *d_out, size_t height, size_t width,
                                          unsigned added_bits, uint32_t shift_monty, void *stream);
+/* prepare_compute_plan (backend_vulkan.rs:959-975): the reference's VulkanComputePlan carries, next to the stage parameters, the
+ * LAUNCH GEOMETRY of its plan (`dispatch`: workgroup counts of one stage; the host then loops log2(height) such dispatches,
+ * :1182-1294).  The hip backend's plan for dft_batch / idft_batch of a height x width matrix is a handful of LDS-tiled passes:
+ * *n_passes = kernel launches, stages_per_pass[i] = radix-2 stages pass i performs (their sum is log2 height; at most `cap` entries
+ * are written).  Host-only: no GPU is touched. */
+int p3hip_dft_plan_bb31(size_t height, size_t width, uint32_t *stages_per_pass, size_t cap, size_t *n_passes);
 /* write_bit_reversed_rows_u32 (backend_vulkan.rs:1005-1026) on device */
 int p3hip_bit_reverse_rows_dev(const uint32_t *d_in, uint32_t *d_out, size_t height, size_t width, void *stream);
 

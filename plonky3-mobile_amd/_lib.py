@@ -35,6 +35,7 @@ _SIGS = {
     "p3hip_coset_lde_from_coeffs_bb31_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint, C.c_uint32,
                                                        C.c_void_p]),
     "p3hip_bit_reverse_rows_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "p3hip_dft_plan_bb31": (C.c_int, [C.c_size_t, C.c_size_t, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_size_t)]),
     "p3hip_fib_trace_dev": (C.c_int, [C.c_uint64, C.c_uint64, C.c_size_t, C.c_void_p, C.c_void_p]),
     "p3hip_poseidon2_permute_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "p3hip_poseidon2_permute": (C.c_int, [C.c_void_p, C.c_size_t]),

@@ -247,6 +247,21 @@ int p3hip_coset_lde_from_coeffs_bb31_dev(const uint32_t* coeffs, uint32_t* out, 
         return ntt_coset_lde_from_coeffs(*cx, st, coeffs, out, cx->ws(st, 2).as<uint32_t>(), h, (uint32_t)w, added_bits, shift);
     });
 }
+int p3hip_dft_plan_bb31(size_t height, size_t width, uint32_t* stages_per_pass, size_t cap, size_t* n_passes) {
+    return guarded([&]() -> int {
+        if (!n_passes) return fail(ERR_BAD_ARG, "dft_plan: null argument");
+        *n_passes = 0;
+        if (height == 0 || width == 0) return OK;
+        if (!is_pow2(height)) return fail(ERR_BAD_ARG, "hip backend requires power-of-two height, got " + std::to_string(height));
+        const uint32_t n = log2u(height);
+        if (n > bb::TWO_ADICITY) return fail(ERR_BAD_ARG, "height exceeds BabyBear two-adicity");
+        const std::vector<uint32_t> d = ntt_dft_plan(n);
+        *n_passes = d.size();
+        for (size_t i = 0; i < d.size() && i < cap; i++) if (stages_per_pass) stages_per_pass[i] = d[i];
+        return OK;
+    });
+}
+
 int p3hip_bit_reverse_rows_dev(const uint32_t* in, uint32_t* out, size_t h, size_t w, void* stream) {
     return guarded([&]() -> int {
         if (h == 0 || w == 0) return OK;

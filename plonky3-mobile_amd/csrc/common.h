@@ -106,6 +106,7 @@ void release_thread_contexts();
 // dft: natural order in, natural order out (TwoAdicSubgroupDft::dft_batch).  inverse=true gives idft_batch.
 int ntt_dft(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* dst, uint64_t height,
             uint32_t width, bool inverse);
+std::vector<uint32_t> ntt_dft_plan(uint32_t n);  // stages per pass (= per launch) of dft / idft over 2^n rows; host-only
 // coset_lde: src = evaluations over the order-`height` subgroup (natural order), dst =
 // (height << added_bits) x width evaluations over shift*<g>, natural or bit-reversed row order.
 int ntt_coset_lde(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* dst, uint64_t height,

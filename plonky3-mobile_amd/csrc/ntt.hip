@@ -1088,6 +1088,10 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
 
 }  // namespace
 
+// The passes dft_batch / idft_batch run for 2^n rows: one kernel launch per entry, entry = radix-2 stages done by that pass, in
+// launch order (run_dit walks the digits lowest position first).  Host-only.
+std::vector<uint32_t> ntt_dft_plan(uint32_t n) { return split_digits(n); }
+
 int ntt_dft(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* dst, uint64_t height,
             uint32_t width, bool inverse) {
     if (!height || !width) return OK;

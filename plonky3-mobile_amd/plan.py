@@ -1,17 +1,18 @@
 """Host-side mirror of the reference's plan / parameter helpers (native/src/backend_vulkan.rs:784-1031), for callers
 written against that surface (the reference's own benchmark drives the raw-u32 entry, fib_air.rs:128-134):
 
-  FftStageParams / params_for_stage    backend_vulkan.rs:784-808   the 32-byte #[repr(C)] parameter block
-  ComputePlan / prepare_compute_plan   :959-975                    params + dispatch dimensions
-  dispatch_dims                        :818-839
+  FftStageParams / params_for_stage    backend_vulkan.rs:784-808   width, height, stage, log_n, twiddle_base
+  ComputePlan / prepare_compute_plan   :959-975                    params + the LAUNCH PLAN of the backend
   twiddles_for_stage / twiddle_table   :977-996                    stage s at offset 2^s - 1, H - 1 words in all
   reverse_bits_len / write_bit_reversed_rows_u32   :998-1026
   setup_pipeline_plan(plan, words)     :1028-1031                  Montgomery words in natural row order in and out
 
-On MI355X the per-stage dispatch loop these describe does not exist: setup_pipeline_plan hands the whole transform to
-libp3hip (1-3 LDS-tiled passes), and the device never streams the H - 1 word table — the host functions below
-exist for parity of the surface and are pure integer code (no device)."""
-import struct
+The reference's VulkanComputePlan carries the workgroup counts of ONE stage dispatch (the host loops log2(height) of them)
+and the length of a SPIR-V blob.  Neither exists here: `ComputePlan.dispatch` is what libp3hip will actually launch for the
+shape — the radix-2 stages of each LDS-tiled pass, one kernel launch per entry (p3hip_dft_plan_bb31, host-only) — and the
+device never streams the H - 1 word twiddle table; twiddle_table / write_bit_reversed_rows_u32 below are the reference's
+layouts as pure integer code, used by the tests that pin the CPU restatement to them."""
+import ctypes as C
 from dataclasses import dataclass
 
 import numpy as np
@@ -34,40 +35,36 @@ def two_adic_generator(bits):
 
 
 @dataclass
-class FftStageParams:  # #[repr(C)], 32 bytes
+class FftStageParams:  # backend_vulkan.rs:784-795 (the three padding words of the #[repr(C)] uniform block have no meaning here)
     width: int
     height: int
     stage: int
     log_n: int
     twiddle_base: int
-    _pad0: int = 0
-    _pad1: int = 0
-    _pad2: int = 0
-
-    def pack(self):
-        return struct.pack("<8I", self.width, self.height, self.stage, self.log_n, self.twiddle_base, 0, 0, 0)
 
 
 def params_for_stage(width, height, stage, log_n, twiddle_base):
     return FftStageParams(width, height, stage, log_n, twiddle_base)
 
 
-def dispatch_dims(params):
-    """ceil(width / 8) x ceil((height / 2) / 8) x 1 workgroups of 8 x 8 (backend_vulkan.rs:818-839)"""
-    half = max(params.height // 2, 1)
-    return ((params.width + 7) // 8, (half + 7) // 8, 1)
+def launch_plan(height, width):
+    """radix-2 stages per pass (= per kernel launch) of dft_batch / idft_batch for a height x width matrix, from the library"""
+    from . import _lib
+    n = C.c_size_t(0)
+    buf = (C.c_uint32 * 8)()
+    _lib.check(_lib.lib().p3hip_dft_plan_bb31(height, width, buf, 8, C.byref(n)))
+    return tuple(int(buf[i]) for i in range(min(n.value, 8)))
 
 
 @dataclass
 class ComputePlan:
     params: FftStageParams
-    dispatch: tuple
-    spv_len: int = 0  # no SPIR-V here: the kernels live in libp3hip.so
+    dispatch: tuple  # the hip backend's launch plan: stages per LDS-tiled pass, one launch each (sum = log2 height)
 
 
 def prepare_compute_plan(width, height, stage, log_n):
     params = params_for_stage(width, height, stage, log_n, 1)
-    return ComputePlan(params, dispatch_dims(params))
+    return ComputePlan(params, launch_plan(height, width))
 
 
 def twiddles_for_stage(log_n, stage):

@@ -32,6 +32,12 @@ for hash_name, kind in (("poseidon2", o.HASH_POSEIDON2), ("keccak", o.HASH_KECCA
     pr = p3.FibAirProver(13, params=gfp, hash=hash_name)
     assert pr.prove(2, 3) == o.prove_fib_air(2, 3, 13, ofp, hash=kind), hash_name
     pr.close()
+if os.environ.get("P3HIP_FRI_TAIL") == "1":
+    # the single-launch FRI tail: proofs that are ALL tail (LDE of at most 2^8 rows), proofs with a final polynomial, blowup 4 and 8
+    for log_n, t in ((1, (1, 0, 4, 2)), (3, (2, 2, 6, 5)), (6, (1, 0, 9, 5)), (7, (1, 3, 9, 0)), (9, (3, 1, 4, 10)), (10, (1, 0, 20, 8)), (12, (2, 0, 10, 4))):
+        pr = p3.FibAirProver(log_n, params=p3.FriParameters(*t))
+        assert pr.prove(3, 5) == o.prove_fib_air(3, 5, log_n, o.FriParams(*t)), ("fri tail", log_n, t)
+        pr.close()
 # the narrow three-launch coset LDE (2^16 rows and up) in whichever arithmetic the environment selects: integer or fp64
 # butterflies (P3HIP_NTT_NARROW_F64), column pairs or single columns, one or two LDS tiles
 dft = p3.GpuDft.with_backend(p3.BackendKind.Hip)

@@ -31,9 +31,9 @@ VARIANTS = [
     {"P3HIP_LEAF_SALTED": "0", "P3HIP_RNG_SMALL": "0", "P3HIP_HIDING_RNG_SIDE": "0"},
     {"P3HIP_RNG_SUB_LOG": "2", "P3HIP_RNG_SMALL": "0"},
     {"P3HIP_RNG_SUB_LOG": "1", "P3HIP_RNG_SMALL": "0"},
-    {"P3HIP_FRI_TAIL": "1"},                                             # the FRI tail (layers of <= 2^7 rows) in one single-workgroup launch
-    {"P3HIP_HIDING_R_SIDE": "1"},                                        # the randomization commitment on a second side stream (latency switch)
-    {"P3HIP_Q4_MAX_LOG": "15"},                                          # one Poseidon2 state per DPP quad for layers of 2^12..2^15 digests (latency switch)
+    # the latency switches together: the FRI tail (layers of <= 2^7 rows) in one single-workgroup launch, the hiding prover's randomization
+    # commitment on a second side stream, one Poseidon2 state per DPP quad for layers of 2^12..2^15 digests
+    {"P3HIP_FRI_TAIL": "1", "P3HIP_HIDING_R_SIDE": "1", "P3HIP_Q4_MAX_LOG": "15"},
     {"P3HIP_Q4_MAX_LOG": "14", "P3HIP_Q4_PRIO": "0", "P3HIP_COOP_MAX_LOG": "9"},
 ]
 

@@ -197,3 +197,29 @@ def test_hiding_mmcs_commit_and_openings(p3, oracle, hash):
             dims = [(m.shape[0], m.shape[1]) for m in inter]
             assert oracle.mmcs_verify_batch(root, dims, index, got, path, kind=kind)
         tree.free()
+
+
+def test_hiding_provers_concurrently_keep_their_bytes(p3, oracle):
+    """Four hiding provers on four host threads (each with its main stream and its fill side stream) prove the same three instances
+    over and over: every proof equals the oracle's.  A missed cross-stream dependency — a fill racing its consumer — would differ."""
+    import threading
+    import torch
+    gfp, ofp = _fp(p3, oracle, 1, 0, 12, 6)
+    log_n, insts = 13, [(0, 1), (3, 4), (9, 2)]
+    ref = {ab: oracle.prove_fib_air_hiding(ab[0], ab[1], log_n, ofp, hash=oracle.HASH_KECCAK, seed=1) for ab in insts}
+    bad = []
+
+    def worker(k):
+        torch.cuda.set_device(0)
+        pr = p3.FibAirProver(log_n, params=gfp, hash="keccak", hiding=True, seed=1)
+        for r in range(18):
+            ab = insts[(r + k) % 3]
+            if pr.prove(*ab) != ref[ab]:
+                bad.append((k, r, ab))
+        pr.close()
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not bad, bad[:5]

@@ -50,6 +50,10 @@ static int is_pow2(size_t n) { return n && !(n & (n - 1)); }
 
 /* backend_vulkan.rs:977-996 twiddles_for_stage / twiddle_table:
  * stage s holds step^0..step^(2^s-1), step = root^(2^(log_n-s-1)); stage s starts at 2^s-1. */
+/* Rows of BLK consecutive powers are what the OpenMP loops below hand to a thread: a block starts from
+ * bb_pow(base, first index) and multiplies on, so every entry is the same field element as in the serial
+ * recurrence (field arithmetic is exact: same words whatever the thread count; p3o_set_threads(1) IS the serial loop). */
+#define P3O_BLK ((size_t)4096)
 void p3o_twiddle_table(unsigned log_n, uint32_t *out) {
     uint32_t root = bb_two_adic_generator(log_n);
     for (unsigned stage = 0; stage < log_n; stage++) {
@@ -57,8 +61,13 @@ void p3o_twiddle_table(unsigned log_n, uint32_t *out) {
         for (unsigned i = 0; i < log_n - stage - 1; i++) step = bb_mul(step, step);
         size_t half = (size_t)1 << stage;
         uint32_t *dst = out + (half - 1);
-        uint32_t acc = BB_ONE;
-        for (size_t i = 0; i < half; i++) { dst[i] = acc; acc = bb_mul(acc, step); }
+        size_t nblk = (half + P3O_BLK - 1) / P3O_BLK;
+        #pragma omp parallel for schedule(static) if (nblk > 1)
+        for (size_t b = 0; b < nblk; b++) {
+            size_t lo = b * P3O_BLK, hi = lo + P3O_BLK < half ? lo + P3O_BLK : half;
+            uint32_t acc = bb_pow(step, lo);
+            for (size_t i = lo; i < hi; i++) { dst[i] = acc; acc = bb_mul(acc, step); }
+        }
     }
 }
 
@@ -72,6 +81,7 @@ void p3o_bit_reverse_rows(uint32_t *dst, const uint32_t *src, size_t height, siz
     if (!width || !height) return;
     if (!is_pow2(height)) { memcpy(dst, src, height * width * 4); return; }
     unsigned bits = log2_exact(height);
+    #pragma omp parallel for schedule(static) if (height >= 4096)
     for (size_t row = 0; row < height; row++)
         memcpy(dst + row * width, src + reverse_bits_len(row, bits) * width, width * 4);
 }
@@ -81,6 +91,8 @@ void p3o_bit_reverse_rows(uint32_t *dst, const uint32_t *src, size_t height, siz
 void p3o_stage_in_place(uint32_t *data, size_t width, size_t height, unsigned stage,
                         const uint32_t *tw) {
     size_t m = (size_t)1 << (stage + 1), half = m >> 1;
+    /* the butterflies of one stage touch disjoint row pairs: threads over j */
+    #pragma omp parallel for schedule(static) if (height >= 8192)
     for (size_t j = 0; j < height / 2; j++) {
         size_t block = j / half, offset = j % half;
         size_t base = block * m + offset;
@@ -138,6 +150,7 @@ int p3o_idft_batch(const uint32_t *in, uint32_t *out, size_t height, size_t widt
     int rc = p3o_dft_batch(in, tmp, height, width);
     if (rc) { free(tmp); return rc; }
     uint32_t hinv = bb_inv(bb_to_monty((uint32_t)height));
+    #pragma omp parallel for schedule(static) if (height >= 4096)
     for (size_t r = 0; r < height; r++) {
         size_t src = r ? height - r : 0;
         for (size_t c = 0; c < width; c++) out[r * width + c] = bb_mul(tmp[src * width + c], hinv);
@@ -151,10 +164,15 @@ int p3o_coset_dft_batch(const uint32_t *in, uint32_t *out, size_t height, size_t
                         uint32_t shift) {
     if (!height || !width) return 0;
     uint32_t *tmp = malloc(height * width * 4);
-    uint32_t wgt = BB_ONE;
-    for (size_t r = 0; r < height; r++) {
-        for (size_t c = 0; c < width; c++) tmp[r * width + c] = bb_mul(in[r * width + c], wgt);
-        wgt = bb_mul(wgt, shift);
+    size_t nblk = (height + P3O_BLK - 1) / P3O_BLK;
+    #pragma omp parallel for schedule(static) if (nblk > 1)
+    for (size_t b = 0; b < nblk; b++) {
+        size_t lo = b * P3O_BLK, hi = lo + P3O_BLK < height ? lo + P3O_BLK : height;
+        uint32_t wgt = bb_pow(shift, lo);
+        for (size_t r = lo; r < hi; r++) {
+            for (size_t c = 0; c < width; c++) tmp[r * width + c] = bb_mul(in[r * width + c], wgt);
+            wgt = bb_mul(wgt, shift);
+        }
     }
     int rc = p3o_dft_batch(tmp, out, height, width);
     free(tmp);

@@ -47,7 +47,7 @@ int p3o_prove_fib_air_hash(int hash, uint64_t a, uint64_t b, unsigned log_n, uns
     { uint32_t g = bb_two_adic_generator(log_n), ginv = bb_inv(g);
       uint32_t zh = bb_sub(bb_pow(gen, n), BB_ONE), zh_inv = bb_inv(zh);
       uint32_t *xq = malloc(n * 4);
-      { uint32_t xx = gen; for (size_t i = 0; i < n; i++) { xq[i] = xx; xx = bb_mul(xx, g); } }
+      power_table(xq, n, gen, g);
       #pragma omp parallel for schedule(static)
       for (size_t i = 0; i < n; i++) {
           uint32_t x = xq[i];
@@ -84,8 +84,8 @@ int p3o_prove_fib_air_hash(int hash, uint64_t a, uint64_t b, unsigned log_n, uns
       for (int j = 0; j < 2; j++) { ry0 = bb4_add(ry0, bb4_mul(alp[j], t_loc[j])); ry1 = bb4_add(ry1, bb4_mul(alp[j], t_nxt[j])); }
       for (int j = 0; j < 4; j++) ry2 = bb4_add(ry2, bb4_mul(alp[j], q_z[j]));
       uint32_t g = bb_two_adic_generator(log_big);
-      uint32_t *xs = malloc(big * 4); uint32_t x = gen;
-      for (size_t i = 0; i < big; i++) { xs[i] = x; x = bb_mul(x, g); }
+      uint32_t *xs = malloc(big * 4);
+      power_table(xs, big, gen, g);
       #pragma omp parallel for schedule(static)
       for (size_t i = 0; i < big; i++) {
           uint32_t xi = xs[rev_bits(i, log_big)];

@@ -130,19 +130,43 @@ static P3O_UNUSED bb4_t fib_fold_base(const uint32_t loc[2], const uint32_t nxt[
 static P3O_UNUSED void interpolate_low_coset(const uint32_t *lde_br, size_t h, size_t w, uint32_t shift, bb4_t z, bb4_t *ys) {
     unsigned lh = 0; while (((size_t)1 << lh) < h) lh++;
     uint32_t g = bb_two_adic_generator(lh);
-    for (size_t c = 0; c < w; c++) ys[c] = bb4_zero();
-    uint32_t x = shift;
-    for (size_t i = 0; i < h; i++) {
-        bb4_t d = bb4_inv(bb4_sub(z, bb4_from_base(x)));
-        const uint32_t *row = lde_br + rev_bits(i, lh) * w;
-        bb4_t dx = bb4_scale(d, x);
-        for (size_t c = 0; c < w; c++) ys[c] = bb4_add(ys[c], bb4_scale(dx, row[c]));
-        x = bb_mul(x, g);
+    /* blocks of consecutive points, one partial sum per block and column, added up in block order afterwards: field
+     * addition is exact, so the words do not depend on the thread count (the multi-core leg of bench.py's cpu_baseline) */
+    const size_t BLK = 1024, nblk = (h + BLK - 1) / BLK;
+    bb4_t *part = malloc(nblk * w * sizeof(bb4_t));
+    #pragma omp parallel for schedule(static) if (nblk > 1)
+    for (size_t b = 0; b < nblk; b++) {
+        size_t lo = b * BLK, hi = lo + BLK < h ? lo + BLK : h;
+        bb4_t *acc = part + b * w;
+        for (size_t c = 0; c < w; c++) acc[c] = bb4_zero();
+        uint32_t x = bb_mul(shift, bb_pow(g, lo));
+        for (size_t i = lo; i < hi; i++) {
+            bb4_t d = bb4_inv(bb4_sub(z, bb4_from_base(x)));
+            const uint32_t *row = lde_br + rev_bits(i, lh) * w;
+            bb4_t dx = bb4_scale(d, x);
+            for (size_t c = 0; c < w; c++) acc[c] = bb4_add(acc[c], bb4_scale(dx, row[c]));
+            x = bb_mul(x, g);
+        }
     }
+    for (size_t c = 0; c < w; c++) ys[c] = bb4_zero();
+    for (size_t b = 0; b < nblk; b++)
+        for (size_t c = 0; c < w; c++) ys[c] = bb4_add(ys[c], part[b * w + c]);
+    free(part);
     uint32_t sh = bb_pow(shift, h);
     bb4_t zh = bb4_pow(z, h);
     bb4_t f = bb4_scale(bb4_sub(zh, bb4_from_base(sh)), bb_inv(bb_mul(bb_to_monty((uint32_t)h), sh)));
     for (size_t c = 0; c < w; c++) ys[c] = bb4_mul(ys[c], f);
+}
+
+/* out[i] = first * step^i for i < n, in blocks (threads; the same words as the serial recurrence) */
+static P3O_UNUSED void power_table(uint32_t *out, size_t n, uint32_t first, uint32_t step) {
+    const size_t BLK = 4096, nblk = (n + BLK - 1) / BLK;
+    #pragma omp parallel for schedule(static) if (nblk > 1)
+    for (size_t b = 0; b < nblk; b++) {
+        size_t lo = b * BLK, hi = lo + BLK < n ? lo + BLK : n;
+        uint32_t acc = bb_mul(first, bb_pow(step, lo));
+        for (size_t i = lo; i < hi; i++) { out[i] = acc; acc = bb_mul(acc, step); }
+    }
 }
 
 typedef struct { unsigned log_blowup, log_final_poly_len, num_queries, pow_bits; } fri_params_t;
@@ -156,8 +180,7 @@ static P3O_UNUSED void fold_matrix(const bb4_t *in, size_t len, bb4_t beta, bb4_
     uint32_t one_half = bb_inv(bb_to_monty(2));
     bb4_t hb = bb4_scale(beta, one_half);
     uint32_t *pw = malloc((half ? half : 1) * 4);
-    uint32_t acc = BB_ONE;
-    for (size_t i = 0; i < half; i++) { pw[i] = acc; acc = bb_mul(acc, ginv); }
+    power_table(pw, half, BB_ONE, ginv);
     #pragma omp parallel for schedule(static) if (half >= 4096)
     for (size_t i = 0; i < half; i++) {
         bb4_t power = bb4_scale(hb, pw[rev_bits(i, lh)]);

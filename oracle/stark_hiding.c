@@ -136,7 +136,7 @@ int p3o_prove_fib_air_hiding(int hash, uint64_t a, uint64_t b, unsigned log_n, u
     for (int c = 0; c < HID_CHUNKS; c++) qchunk[c] = malloc(h * HID_D * 4);
     { uint32_t g4 = bb_two_adic_generator(log_q), gh_inv = bb_inv(bb_two_adic_generator(log_n));
       uint32_t *xq = malloc(qn * 4);
-      { uint32_t xx = gen; for (size_t i = 0; i < qn; i++) { xq[i] = xx; xx = bb_mul(xx, g4); } }
+      power_table(xq, qn, gen, g4);
       #pragma omp parallel for schedule(static)
       for (size_t i = 0; i < qn; i++) {
           uint32_t x = xq[i];
@@ -156,6 +156,7 @@ int p3o_prove_fib_air_hiding(int hash, uint64_t a, uint64_t b, unsigned log_n, u
     for (int c = 0; c < HID_CHUNKS - 1; c++) tcoef[c] = rand_matrix(&rng_pcs, h, HID_D);
     tcoef[HID_CHUNKS - 1] = malloc(h * HID_D * 4);
     { uint32_t kinv[HID_CHUNKS]; for (int c = 0; c < HID_CHUNKS; c++) kinv[c] = bb_inv(kc[c]);
+      #pragma omp parallel for schedule(static) if (h >= 4096)
       for (size_t i = 0; i < h * HID_D; i++) {
           uint32_t s = 0;
           for (int c = 0; c < HID_CHUNKS - 1; c++) s = bb_add(s, bb_mul(tcoef[c][i], kinv[c]));
@@ -165,15 +166,18 @@ int p3o_prove_fib_air_hiding(int hash, uint64_t a, uint64_t b, unsigned log_n, u
     for (int c = 0; c < HID_CHUNKS; c++) {
         uint32_t *co = malloc(h * HID_D * 4), *ext = calloc(big * HID_D, 4), *nat = malloc(big * HID_D * 4);
         p3o_idft_batch(qchunk[c], co, h, HID_D);  /* coefficients of q_c(s_c X) */
-        uint32_t s_c = bb_mul(gen, bb_pow(bb_two_adic_generator(log_q), (uint64_t)c)), sinv = bb_inv(s_c), p = BB_ONE;
+        uint32_t s_c = bb_mul(gen, bb_pow(bb_two_adic_generator(log_q), (uint64_t)c)), sinv = bb_inv(s_c);
+        uint32_t *spw = malloc(h * 4);
+        power_table(spw, h, BB_ONE, sinv);
+        #pragma omp parallel for schedule(static) if (h >= 4096)
         for (size_t k = 0; k < h; k++) {
             for (int j = 0; j < HID_D; j++) {
-                uint32_t ak = bb_mul(co[k * HID_D + j], p);
+                uint32_t ak = bb_mul(co[k * HID_D + j], spw[k]);
                 ext[k * HID_D + j] = bb_sub(ak, bb_mul(sh[c], tcoef[c][k * HID_D + j]));
                 ext[(h + k) * HID_D + j] = tcoef[c][k * HID_D + j];
             }
-            p = bb_mul(p, sinv);
         }
+        free(spw);
         p3o_coset_dft_batch(ext, nat, big, HID_D, gen);
         lde_q[c] = malloc(big * HID_D * 4);
         p3o_bit_reverse_rows(lde_q[c], nat, big, HID_D);
@@ -208,8 +212,8 @@ int p3o_prove_fib_air_hiding(int hash, uint64_t a, uint64_t b, unsigned log_n, u
     /* reduced openings over the LDE domain, committed order */
     bb4_t *ro = malloc(big * sizeof(bb4_t));
     { uint32_t g = bb_two_adic_generator(log_big);
-      uint32_t *xs = malloc(big * 4); uint32_t x = gen;
-      for (size_t i = 0; i < big; i++) { xs[i] = x; x = bb_mul(x, g); }
+      uint32_t *xs = malloc(big * 4);
+      power_table(xs, big, gen, g);
       #pragma omp parallel for schedule(static)
       for (size_t i = 0; i < big; i++) {
           uint32_t xi = xs[rev_bits(i, log_big)];

@@ -124,6 +124,7 @@ def cpu_baseline_wide(job):
 
 
 HOST_CORES, PINNING = [], "not evaluated"
+PG_NOTE = ""
 
 
 def other_workloads(budget_s=240.0, child_timeout_s=120.0):
@@ -333,10 +334,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        from plonky3_mobile_amd import batch as _pbatch  # p3 (load_package above) registered the package
+        global PG_NOTE
+        PG_NOTE = _pbatch.init_process_group_for_batches(backend, local_rank)
     if stub:
         if backend == "nccl":
             raise RuntimeError("P3HIP_BENCH_STUB=1 needs P3HIP_BENCH_BACKEND=gloo")
@@ -451,9 +451,17 @@ def run(args, job, dist, world, rank, local_rank, n_dev, backend, coll_dev, use_
             waits[key] += time.perf_counter() - t_in
         return r
 
+    def scatter_run(first, count):
+        """ONE scatter for a whole run of `count` steps (one scatter in): every step's descriptors are known when the
+        run starts.  It is issued inside the timed region (run_steps), on the collective stream, and nothing blocks on it: the first
+        issue() waits for the event behind its pinned landing copy."""
+        steps = [[(k * n_total + i, k * n_total + i + 1) for i in range(n_total)] for k in range(first, first + count)] if rank == 0 else []
+        coll_state["descriptors"] = timed("scatter_wait_s", lambda: pbatch.scatter_descriptor_steps(steps, device=coll_dev, shape=(count, n_total)))
+        coll_state["descriptors_first"] = first
+        coll_state["scatters"] = coll_state.get("scatters", 0) + 1
+
     def descriptors(k):
-        inst = [(k * n_total + i, k * n_total + i + 1) for i in range(n_total)] if rank == 0 else []
-        return timed("scatter_wait_s", lambda: pbatch.scatter_descriptors(inst, device=coll_dev))
+        return timed("scatter_wait_s", lambda: coll_state["descriptors"].step(k - coll_state["descriptors_first"]))
 
     # Steps are PIPELINED (depth 1): step k + 1 is issued — its instances dealt to the prover threads' queue — before
     # step k retires, so a prover that has finished its share of step k starts on step k + 1 at once instead of
@@ -509,6 +517,8 @@ def run(args, job, dist, world, rank, local_rank, n_dev, backend, coll_dev, use_
         try:
             if count <= 0:
                 return
+            if use_gather:
+                scatter_run(first, count)
             inflight = [issue(first)]
             for k in range(first + 1, first + count):
                 inflight.append(issue(k))
@@ -582,7 +592,8 @@ def run(args, job, dist, world, rank, local_rank, n_dev, backend, coll_dev, use_
                        parallelism=("independent proofs, instance i -> rank i mod N; RCCL only scatters descriptors / gathers proof bytes"
                                     if args.workload != "cfg5" else "replicas only (one matrix per rank, no collective)")),
         "roofline": roof,
-        "collectives": coll_state["mode"],
+        "collectives": coll_state["mode"] + ((" [%s; one descriptor scatter per run (%d in the timed region), one gather per step on a "
+                                               "highest-priority stream of their own]" % (PG_NOTE, 1)) if use_gather else ""),
         "world_size": world,
         "dist_backend": (backend + (" (= RCCL on ROCm)" if backend == "nccl" else "")) if use_dist else None,
         "ranks": ranks_info,
@@ -590,6 +601,7 @@ def run(args, job, dist, world, rank, local_rank, n_dev, backend, coll_dev, use_
                       "descriptor scatter / in retire() on the proof gather / joining its own provers, host cores in its affinity mask; "
                       "host_core_list and pinning are rank 0's (every rank applies the same rule to its own GPU)",
         "gather_bytes_per_step": (n_total * coll_state["width"]) if use_gather and "width" in coll_state else 0,
+        "descriptor_scatters_in_timed_region": (1 if args.steps > 0 else 0) if use_gather else 0,
         "parity": "proof bytes / digests are compared with the repo's C oracle (a restatement of upstream Plonky3 from "
                   "recall; pinned by reference code only for the DFT): self-consistent, upstream parity UNPINNED",
     }

@@ -2,10 +2,19 @@
 
 Proofs are independent, so there is no collective on the data path: instance i goes to rank i mod world.
 torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests) is used only to
-scatter the instance descriptors (a, b) from rank 0 and to gather the proof bytes back."""
+scatter the instance descriptors (a, b) from rank 0 and to gather the proof bytes back.
+
+Round 5: the collectives never share a queue with the provers.  On a GPU backend they run on a stream of their
+own at the highest priority the device offers (`collective_stream`; `init_process_group_for_batches` also asks
+RCCL for its high-priority internal stream), a whole run's descriptors travel in ONE scatter
+(`scatter_descriptor_steps`: SURVEY.md §8e "one scatter in"), a step's proofs and their (index, length) headers
+travel in ONE gather (the header is the first 16 bytes of every staging row), and the host never blocks on a
+device round trip while issuing work: results are waited for through events recorded behind pinned copies."""
 import numpy as np
 import torch
 import torch.distributed as dist
+
+ROW_HEADER = 16  # bytes in front of every staging row: int64 instance index (-1 = empty row), int64 proof length
 
 
 def shard_instances(n_total, rank, world):
@@ -13,50 +22,153 @@ def shard_instances(n_total, rank, world):
     return list(range(rank, n_total, world))
 
 
-def scatter_descriptors(instances, device="cpu"):
-    """Rank 0 holds `instances` = list of (a, b); every rank receives its shard (list of (index, a, b))."""
+_STREAMS = {}
+
+
+def collective_stream(device):
+    """The stream the batch collectives and their staging copies run on: one per device, highest priority, so that
+    RCCL's kernels and the copies are scheduled ahead of the provers' queued launches instead of behind them.
+    None on the CPU (gloo) path."""
+    if str(device) == "cpu":
+        return None
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    s = _STREAMS.get(idx)
+    if s is None:
+        try:
+            hi = torch.cuda.Stream.priority_range()[1]  # (least, greatest): numerically lower = higher priority
+        except Exception:  # noqa: BLE001 - older torch: -1 is "high"
+            hi = -1
+        s = _STREAMS[idx] = torch.cuda.Stream(device=idx, priority=min(hi, -1))
+    return s
+
+
+def init_process_group_for_batches(backend, local_rank=0):
+    """init_process_group for the scatter / gather of batches.  "nccl" (= RCCL on ROCm): bound to this rank's device and with
+    RCCL's own stream at high priority, so a collective issued while four provers saturate the compute queues does not wait
+    for their launches to drain (round 4 measured 8.5 ms per 24-byte descriptor scatter at one rank).  Returns a short
+    description for the bench line."""
+    if backend != "nccl":
+        dist.init_process_group(backend)
+        return backend + " (rehearsal, not RCCL)"
+    note = "rccl, process-group stream at high priority"
+    try:
+        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), pg_options=opts)
+    except (AttributeError, TypeError):
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        note = "rccl, default-priority process-group stream (this torch has no ProcessGroupNCCL.Options)"
+    return note
+
+
+class _Landing:
+    """A small device -> pinned-host copy with an event behind it (no blocking .cpu() on the issue path)."""
+
+    def __init__(self, dev_tensor, stream):
+        self.host = torch.empty(dev_tensor.shape, dtype=dev_tensor.dtype).pin_memory()
+        self.host.copy_(dev_tensor, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record(stream)
+        self.keep = dev_tensor
+
+    def tolist(self):
+        self.event.synchronize()
+        return self.host.tolist()
+
+
+def _on(stream):
+    return torch.cuda.stream(stream) if stream is not None else _Null()
+
+
+class _Null:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+class PendingDescriptors:
+    """The descriptors of several steps, scattered in one collective; step(k) gives this rank's shard of step k as a list of
+    (index, a, b).  The first call waits for the one event behind the pinned copy."""
+
+    def __init__(self, landing, steps, per):
+        self._landing, self._steps, self._per, self._rows = landing, steps, per, None
+
+    def step(self, k):
+        if self._rows is None:
+            self._rows = self._landing.tolist()
+            self._landing = None
+        rows = self._rows[k * self._per:(k + 1) * self._per]
+        return [(int(i), int(a), int(b)) for i, a, b in rows if i >= 0]
+
+    def __len__(self):
+        return self._steps
+
+
+def scatter_descriptor_steps(steps, device="cpu", shape=None):
+    """`steps` (rank 0 only; anything on the other ranks): a list with one list of instances (a, b) per step.  ONE scatter moves
+    every step's descriptors; rank r receives, for each step, the instances shard_instances(n, r, world) of that step.
+    `shape` = (number of steps, instances per step) when every rank knows it (bench.py does: nothing but the scatter is
+    issued then, and nothing blocks); without it rank 0's shape is broadcast first.  Returns PendingDescriptors."""
     world, rank = dist.get_world_size(), dist.get_rank()
-    n = torch.tensor([len(instances) if rank == 0 else 0], dtype=torch.int64, device=device)
-    dist.broadcast(n, 0)
-    n = int(n.item())
-    per = (n + world - 1) // world
-    recv = torch.full((per, 3), -1, dtype=torch.int64, device=device)
-    if rank == 0:
-        chunks = []
-        for r in range(world):
-            rows = [(i, instances[i][0], instances[i][1]) for i in shard_instances(n, r, world)]
-            rows += [(-1, 0, 0)] * (per - len(rows))
-            chunks.append(torch.tensor(rows, dtype=torch.int64, device=device).reshape(per, 3))
-        dist.scatter(recv, chunks, src=0)
-    else:
-        dist.scatter(recv, None, src=0)
-    return [(int(i), int(a), int(b)) for i, a, b in recv.cpu().tolist() if i >= 0]
+    stream = collective_stream(device)
+    with _on(stream):
+        if shape is None:
+            t = torch.tensor([len(steps), max([len(s) for s in steps], default=0)] if rank == 0 else [0, 0], dtype=torch.int64)
+            if stream is not None:
+                t = t.pin_memory().to(device, non_blocking=True)
+            dist.broadcast(t, 0)
+            shape = (_Landing(t, stream).tolist() if stream is not None else t.tolist())
+        n_steps, n = int(shape[0]), int(shape[1])
+        if rank == 0 and (len(steps) != n_steps or any(len(s) > n for s in steps)):
+            raise ValueError("scatter_descriptor_steps: %d steps of at most %d instances announced, got %r" % (n_steps, n, [len(s) for s in steps]))
+        per = (n + world - 1) // world
+        recv = torch.full((max(n_steps * per, 1), 3), -1, dtype=torch.int64, device=device)
+        if rank == 0:
+            table = np.full((world, max(n_steps * per, 1), 3), -1, dtype=np.int64)
+            for k, inst in enumerate(steps):
+                for r in range(world):
+                    for j, i in enumerate(shard_instances(len(inst), r, world)):
+                        table[r, k * per + j] = (i, inst[i][0], inst[i][1])
+            host = torch.from_numpy(table)
+            if stream is not None:
+                host = host.pin_memory().to(device, non_blocking=True)
+            dist.scatter(recv, [host[r] for r in range(world)], src=0)
+        else:
+            dist.scatter(recv, None, src=0)
+        landing = _Landing(recv, stream) if stream is not None else recv
+    return PendingDescriptors(landing, n_steps, per)
+
+
+def scatter_descriptors(instances, device="cpu"):
+    """Rank 0 holds `instances` = list of (a, b); every rank receives its shard (list of (index, a, b)).  One step's worth;
+    a run of several steps sends them all at once with scatter_descriptor_steps."""
+    return scatter_descriptor_steps([instances] if dist.get_rank() == 0 else [], device).step(0)
 
 
 class _PendingGather:
-    """An in-flight gather of one step's proofs (two async collectives); wait() returns the proofs on rank 0."""
+    """An in-flight gather of one step's proofs (one async collective); wait() returns the proofs on rank 0."""
 
-    def __init__(self, works, bufs, metas, n_total, keep, landed=None, event=None):
-        self.works, self.bufs, self.metas, self.n_total, self.keep = works, bufs, metas, n_total, keep
-        self.landed, self.event = landed, event
+    def __init__(self, work, rows, n_total, keep, event=None):
+        self.work, self.rows, self.n_total, self.keep, self.event = work, rows, n_total, keep, event
 
     def wait(self, copy=True):
         """Rank 0: all n_total proofs in instance order — bytes objects, or with copy=False uint8 views of the
         receive buffer (valid until the gather after next reuses it).  Other ranks: None."""
         if self.event is not None:
-            self.event.synchronize()  # the collectives and the device -> pinned host copies behind them
+            self.event.synchronize()  # the collective and the device -> pinned host copies behind it
         else:
-            for w in self.works:
-                w.wait()
-        if self.bufs is None:
+            self.work.wait()
+        if self.rows is None:
             return None
         out = [None] * self.n_total
-        bufs, metas = (self.landed if self.landed is not None else (self.bufs, self.metas))
-        for b, m in zip(bufs, metas):
-            b, m = b.numpy(), m.tolist()
-            for k, (i, ln) in enumerate(m):
+        for b in self.rows:
+            b = b.numpy()
+            head = b[:, :ROW_HEADER].copy().view(np.int64)
+            for k, (i, ln) in enumerate(head.tolist()):
                 if i >= 0:
-                    out[i] = b[k, :ln].tobytes() if copy else b[k, :ln]
+                    out[i] = b[k, ROW_HEADER:ROW_HEADER + ln].tobytes() if copy else b[k, ROW_HEADER:ROW_HEADER + ln]
         return out
 
 
@@ -66,9 +178,10 @@ class ProofGatherer:
 
     open(n_local, width) -> (sink, slot): the prover threads call sink(row, index, proof) the moment a proof is
     serialised (the copy into the pinned buffer overlaps the other provers' GPU work); launch(slot) enqueues ONE H2D
-    copy and the two gathers and returns at once.  On a GPU backend rank 0 also enqueues the copies of the received buffers
-    into pinned host memory and an event behind them, so wait() costs no device round trip on the critical path.
-    `width` (bytes per proof slot) must be the same on every rank: proofs of one parameter set have one length, so
+    copy and ONE gather on the collective stream and returns at once.  On a GPU backend rank 0 also enqueues the copies of
+    the received buffers into pinned host memory and an event behind them, so wait() costs no device round trip on the
+    critical path.  A staging row is a 16-byte header (instance index, proof length) followed by `width` proof bytes, so
+    a step is one collective.  `width` must be the same on every rank: proofs of one parameter set have one length, so
     the caller learns it from the first step (gather_proofs_async does the all_reduce) and passes it from then on."""
 
     def __init__(self, n_total, device="cpu"):
@@ -76,6 +189,7 @@ class ProofGatherer:
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.per = (n_total + self.world - 1) // self.world
         self.slots, self.turn = {}, 0
+        self.stream = collective_stream(device)
 
     def _slot(self, width):
         self.turn = (self.turn + 1) % 3
@@ -83,20 +197,16 @@ class ProofGatherer:
         ent = self.slots.get(key)
         if ent is None:
             gpu = self.device != "cpu"
-            h = torch.zeros((self.per, width), dtype=torch.uint8)
-            hm = torch.full((self.per, 2), -1, dtype=torch.int64)
-            ent = {"h": h.pin_memory() if gpu else h, "hm": hm.pin_memory() if gpu else hm}
+            row = ROW_HEADER + ((width + 15) & ~15)
+            h = torch.zeros((self.per, row), dtype=torch.uint8)
+            ent = {"h": h.pin_memory() if gpu else h, "width": width}
             if gpu:
-                ent["d"] = torch.empty((self.per, width), dtype=torch.uint8, device=self.device)
-                ent["dm"] = torch.empty((self.per, 2), dtype=torch.int64, device=self.device)
+                ent["d"] = torch.empty((self.per, row), dtype=torch.uint8, device=self.device)
                 if self.rank == 0:
                     ent["rb"] = [torch.empty_like(ent["d"]) for _ in range(self.world)]
-                    ent["rm"] = [torch.empty_like(ent["dm"]) for _ in range(self.world)]
-                    ent["lb"] = [torch.empty((self.per, width), dtype=torch.uint8).pin_memory() for _ in range(self.world)]
-                    ent["lm"] = [torch.empty((self.per, 2), dtype=torch.int64).pin_memory() for _ in range(self.world)]
+                    ent["lb"] = [torch.empty((self.per, row), dtype=torch.uint8).pin_memory() for _ in range(self.world)]
             elif self.rank == 0:
                 ent["rb"] = [torch.empty_like(ent["h"]) for _ in range(self.world)]
-                ent["rm"] = [torch.empty_like(ent["hm"]) for _ in range(self.world)]
             self.slots[key] = ent
         return ent
 
@@ -104,40 +214,40 @@ class ProofGatherer:
         if n_local > self.per:
             raise ValueError("%d local proofs for %d slots" % (n_local, self.per))
         ent = self._slot(width)
-        host, meta = ent["h"].numpy(), ent["hm"].numpy()
-        meta[:] = -1
+        host = ent["h"].numpy()
+        head = host[:, :ROW_HEADER].view(np.int64)  # (per, 2): index, length
+        head[:, 0] = -1
+        head[:, 1] = 0
 
         def sink(row, index, proof):
             if len(proof) > width:
                 raise ValueError("proof of %d bytes does not fit the agreed slot of %d" % (len(proof), width))
-            host[row, : len(proof)] = np.frombuffer(proof, dtype=np.uint8)
-            meta[row] = (index, len(proof))
+            host[row, ROW_HEADER:ROW_HEADER + len(proof)] = np.frombuffer(proof, dtype=np.uint8)
+            head[row] = (index, len(proof))
         # direct form: the prover writes the proof into the staging row itself (FibAirProver.prove_into) — no bytes object, no copy
         base, stride = ent["h"].data_ptr(), ent["h"].stride(0)
-        sink.row_ptr = lambda row: (base + row * stride, width)
-        sink.set = lambda row, index, length: meta.__setitem__(row, (index, length))
+        sink.row_ptr = lambda row: (base + row * stride + ROW_HEADER, width)
+        sink.set = lambda row, index, length: head.__setitem__(row, (index, length))
         return sink, ent
 
     def launch(self, ent):
         if self.device == "cpu":
-            buf, meta = ent["h"], ent["hm"]
-        else:
-            buf, meta = ent["d"], ent["dm"]
-            buf.copy_(ent["h"], non_blocking=True)
-            meta.copy_(ent["hm"], non_blocking=True)
-        bufs, metas = (ent["rb"], ent["rm"]) if self.rank == 0 else (None, None)
-        works = [dist.gather(buf, bufs, dst=0, async_op=True), dist.gather(meta, metas, dst=0, async_op=True)]
-        landed = event = None
-        if self.device != "cpu":
-            for w in works:
-                w.wait()  # stream-ordered: the current stream waits, the host does not
+            rows = ent["rb"] if self.rank == 0 else None
+            work = dist.gather(ent["h"], rows, dst=0, async_op=True)
+            return _PendingGather(work, rows, self.n_total, ent)
+        with torch.cuda.stream(self.stream):
+            ent["d"].copy_(ent["h"], non_blocking=True)
+            bufs = ent["rb"] if self.rank == 0 else None
+            work = dist.gather(ent["d"], bufs, dst=0, async_op=True)
+            work.wait()  # stream-ordered: the collective stream waits, the host does not
+            rows = None
             if self.rank == 0:
-                for src, dst in zip(bufs + metas, ent["lb"] + ent["lm"]):
+                for src, dst in zip(bufs, ent["lb"]):
                     dst.copy_(src, non_blocking=True)
-                landed = (ent["lb"], ent["lm"])
+                rows = ent["lb"]
             event = torch.cuda.Event()
-            event.record()
-        return _PendingGather(works, bufs, metas, self.n_total, ent, landed, event)
+            event.record(self.stream)
+        return _PendingGather(work, rows, self.n_total, ent, event)
 
 
 _GATHERERS = {}

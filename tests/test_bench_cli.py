@@ -40,6 +40,7 @@ def test_gpus_2_starts_two_ranks_and_gathers_on_rank_0():
         assert r["host_cores"] >= 1 and r["pinned"] in (0, 1)
     assert out["ranks"][0]["pinning"] and out["ranks"][0]["host_core_list"]
     assert out["gather_bytes_per_step"] == 64 * 64  # 64 stub proofs of 64 bytes per step
+    assert out["descriptor_scatters_in_timed_region"] == 1 and "one descriptor scatter per run" in out["collectives"]
 
 
 def test_ranks_pin_to_the_cores_local_to_their_gpu_when_the_list_is_readable():

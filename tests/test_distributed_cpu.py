@@ -185,6 +185,58 @@ def test_pipelined_gatherer_world2():
         assert allp == [b"S%d:%d:%d:%d" % (step, i, 10 * step + i, 10 * step + i + 1) * (1 + i % 3) for i in range(7)], step
 
 
+def _worker_run_scatter(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_package
+    load_package()
+    from plonky3_mobile_amd import batch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # a whole run's descriptors in ONE scatter (bench.py's form: every rank knows the shape), then the same with the shape
+    # learnt from rank 0 and ragged steps (the last one shorter, one empty)
+    steps = [[(100 * k + i, 100 * k + i + 1) for i in range(7)] for k in range(5)] if rank == 0 else []
+    pend = batch.scatter_descriptor_steps(steps, shape=(5, 7))
+    got = [pend.step(k) for k in (3, 0, 4, 1, 2)]  # any order, any number of times
+    ragged = [[(1, 2), (3, 4), (5, 6)], [], [(9, 9)]] if rank == 0 else []
+    pend2 = batch.scatter_descriptor_steps(ragged)
+    got2 = [pend2.step(k) for k in range(len(pend2))]
+    bad = None
+    if rank == 0:
+        try:
+            batch.scatter_descriptor_steps([[(0, 1)] * 4], shape=(1, 3))
+        except ValueError as e:
+            bad = str(e)
+    q.put((rank, got, got2, bad))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_scatter_for_a_whole_run_world2():
+    """scatter_descriptor_steps: five steps' descriptors in one collective; rank r's shard of step k is instance i -> rank
+    i mod world of THAT step; with and without the shape known to every rank; a shape that does not hold the steps is refused
+    before anything is sent."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_run_scatter, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for rank, got, got2, bad in res:
+        for k, shard in zip((3, 0, 4, 1, 2), got):
+            assert shard == [(i, 100 * k + i, 100 * k + i + 1) for i in range(rank, 7, 2)], (rank, k)
+        ragged = [[(1, 2), (3, 4), (5, 6)], [], [(9, 9)]]
+        assert got2 == [[(i, a, b) for i, (a, b) in enumerate(st) if i % 2 == rank] for st in ragged], rank
+        assert (bad is not None and "announced" in bad) if rank == 0 else bad is None
+
+
 def test_shard_instances_partition():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import load_package

@@ -186,6 +186,23 @@ typedef struct {
     uint32_t proof_of_work_bits;
 } p3hip_fri_params_t;
 typedef struct p3hip_fib_prover p3hip_fib_prover_t;
+/* PROFILES — chosen when an object is created, as the reference chooses its backend when GpuDft is constructed
+ * (native/src/gpu_dft.rs:85-92 `with_backend`); nothing is read from the environment.  LATENCY: one proof at a time, which is what
+ * the reference does (app/src/main/java/com/plonky3/android/MainActivity.kt:29-33, native/src/fib_air.rs:56-72): layers of
+ * 2^10..2^15 digests use the forms that shorten a lone proof's chain of dependent launches (one Poseidon2 state per DPP quad,
+ * cooperative Keccak up to 2^12 digests), the hiding prover commits its randomization polynomial on a second side stream, the FRI
+ * rounds of at most 2^7 rows run in one single-workgroup launch.  THROUGHPUT: several provers share the chip and VALU issue is what
+ * is short: the per-lane forms.  Proof bytes, digests and every intermediate are the same under both.
+ * Defaults: p3hip_fib_prover_create* and p3hip_run_fib_air_zk = LATENCY; p3hip_fib_batch_create* with more than one prover =
+ * THROUGHPUT; free functions (p3hip_mmcs_commit*) = the calling thread's profile (LATENCY until p3hip_set_thread_profile). */
+#define P3HIP_PROFILE_THROUGHPUT 1
+#define P3HIP_PROFILE_LATENCY 2
+int p3hip_set_thread_profile(int profile);
+int p3hip_get_thread_profile(void);  /* -1 when the thread has no device context (no HIP device) */
+/* The general creation entry: any hash (P3HIP_HASH_*), hiding != 0 for the reference's MerkleTreeHidingMmcs + HidingFriPcs
+ * (then `seed` seeds its SmallRng streams), any profile.  The create functions below are this one with P3HIP_PROFILE_LATENCY. */
+int p3hip_fib_prover_create_profile(int profile, int hash, int hiding, uint64_t seed, unsigned log_n, const p3hip_fri_params_t *params,
+                                    void *stream, int own_stream, p3hip_fib_prover_t **out);
 /* Allocates the prover's HBM arena for 2^log_n-row traces.  stream: hipStream_t to enqueue on, or pass
  * own_stream != 0 to let the prover create (and own) a non-blocking stream — one prover per host thread. */
 int p3hip_fib_prover_create(unsigned log_n, const p3hip_fri_params_t *params, void *stream, int own_stream,
@@ -265,6 +282,7 @@ int p3hip_mmcs_commit_hiding_dev(int hash, const uint32_t *const *d_mats, const 
  * kernels of the others.  p3hip_fib_batch_prove proves instances (a[i], b[i]) and returns pointers to the proof
  * bytes, valid until the next call on the same batch. */
 typedef struct p3hip_fib_batch p3hip_fib_batch_t;
+/* Profile of the pool's provers: THROUGHPUT when n_provers > 1, LATENCY for a pool of one. */
 int p3hip_fib_batch_create(unsigned log_n, const p3hip_fri_params_t *params, unsigned n_provers,
                            p3hip_fib_batch_t **out);
 /* the pool under either hash configuration (P3HIP_HASH_POSEIDON2 / P3HIP_HASH_KECCAK) */

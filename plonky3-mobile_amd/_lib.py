@@ -60,6 +60,10 @@ _SIGS = {
     "p3hip_mmcs_layer_dev": (C.c_void_p, [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "p3hip_mmcs_open_batch": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "p3hip_mmcs_free": (None, [C.c_void_p]),
+    "p3hip_set_thread_profile": (C.c_int, [C.c_int]),
+    "p3hip_get_thread_profile": (C.c_int, []),
+    "p3hip_fib_prover_create_profile": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint, C.c_void_p, C.c_void_p, C.c_int,
+                                                  C.POINTER(C.c_void_p)]),
     "p3hip_fib_prover_create": (C.c_int, [C.c_uint, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "p3hip_fib_prover_create_hash": (C.c_int, [C.c_int, C.c_uint, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "p3hip_verify_fib_air_hash": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint,

@@ -43,9 +43,9 @@ def lde_valu_view(key, unit_us, algorithmic_bytes):
 
 
 class _Worker(threading.Thread):
-    def __init__(self, device, log_height, params, stagger_s=0.0, hash="poseidon2", hiding=False):
+    def __init__(self, device, log_height, params, stagger_s=0.0, hash="poseidon2", hiding=False, profile="throughput"):
         super().__init__(daemon=True)
-        self.hash, self.hiding = hash, hiding
+        self.hash, self.hiding, self.profile = hash, hiding, profile
         self.ahead = not hiding and os.environ.get("P3HIP_BENCH_AHEAD", "0") == "1"
         self.stagger_s = stagger_s
         self.device, self.log_height, self.params = device, log_height, params
@@ -56,7 +56,9 @@ class _Worker(threading.Thread):
     def run(self):
         try:
             torch.cuda.set_device(self.device)
-            self.prover = FibAirProver(self.log_height, params=self.params, hash=self.hash, hiding=self.hiding)
+            from .fib_air import set_thread_profile
+            set_thread_profile(self.profile)  # of this thread's free MMCS calls; the prover carries its own
+            self.prover = FibAirProver(self.log_height, params=self.params, hash=self.hash, hiding=self.hiding, profile=self.profile)
             self.outbox.put(("ready", None))
         except Exception as e:  # surfaced by the caller
             self.outbox.put(("error", e))
@@ -128,7 +130,9 @@ class FibAirJob:
         self.params = FriParameters(log_blowup=log_blowup)
         self.threads = max(1, min(threads, batch))
         stag = float(os.environ.get("P3HIP_BENCH_STAGGER_MS", "1.0")) * 1e-3
-        self.workers = [_Worker(self.device, log_height, self.params, stag * t, hash, hiding) for t in range(self.threads)]
+        # provers that share the chip run the THROUGHPUT profile; a job of one prover is a lone prover: LATENCY (include/p3hip.h)
+        self.profile = "throughput" if self.threads > 1 else "latency"
+        self.workers = [_Worker(self.device, log_height, self.params, stag * t, hash, hiding, self.profile) for t in range(self.threads)]
         for w in self.workers:
             w.result()
         self.last = None
@@ -157,7 +161,7 @@ class FibAirJob:
 
     def config(self):
         return {"log_height": self.log_height, "width": 2, "log_blowup": self.log_blowup, "batch_per_gpu": self.batch,
-                "concurrent_provers_per_gpu": self.threads, "hiding": self.hiding,
+                "concurrent_provers_per_gpu": self.threads, "hiding": self.hiding, "profile": self.profile,
                 "fri": {"log_final_poly_len": self.params.log_final_poly_len, "num_queries": self.params.num_queries,
                         "proof_of_work_bits": self.params.proof_of_work_bits}}
 

@@ -347,7 +347,7 @@ static int commit_async_kind(int kind, const uint32_t* const* d_mats, const size
         int rc = get_context(&cx);
         if (rc) return rc;
         Tree* t = nullptr;
-        rc = mmcs_commit((hipStream_t)stream, d_mats, heights, widths, n_mats, &t, nullptr, nullptr, kind);
+        rc = mmcs_commit((hipStream_t)stream, d_mats, heights, widths, n_mats, &t, nullptr, nullptr, kind, nullptr, cx->profile);
         if (rc) return rc;
         *tree_out = new p3hip_tree{t};
         return OK;
@@ -377,7 +377,7 @@ int p3hip_mmcs_commit_into_dev(int hash, const uint32_t* const* d_mats, const si
         int rc = get_context(&cx);
         if (rc) return rc;
         Tree* t = nullptr;
-        rc = mmcs_commit((hipStream_t)stream, d_mats, heights, widths, n_mats, &t, d_layers, nullptr, hash);
+        rc = mmcs_commit((hipStream_t)stream, d_mats, heights, widths, n_mats, &t, d_layers, nullptr, hash, nullptr, cx->profile);
         if (rc) return rc;
         *tree_out = new p3hip_tree{t};
         return OK;
@@ -467,18 +467,39 @@ struct p3hip_fib_prover {
     std::unique_ptr<FibProver> plain;         // TwoAdicFriPcs + MerkleTreeMmcs
     std::unique_ptr<FibHidingProver> hiding;  // HidingFriPcs + MerkleTreeHidingMmcs (fib_air.rs:40-65)
     std::vector<uint8_t> last;
+    size_t proof_len = 0;  // length of this prover's proofs, known once one has SUCCEEDED (0 before); never read from `last`
+    int prove(uint64_t a, uint64_t b) {
+        int rc = hiding ? hiding->prove(a, b, &last) : plain->prove(a, b, &last);
+        if (rc) last.clear();  // a failed proof leaves nothing behind that could be mistaken for one
+        else proof_len = last.size();
+        return rc;
+    }
 };
 
 extern "C" {
 
-int p3hip_fib_prover_create(unsigned log_n, const p3hip_fri_params_t* params, void* stream, int own_stream,
-                            p3hip_fib_prover_t** out) {
-    return p3hip_fib_prover_create_hash(HASH_POSEIDON2, log_n, params, stream, own_stream, out);
+int p3hip_set_thread_profile(int profile) {
+    return guarded([&]() -> int {
+        if (profile != P3HIP_PROFILE_THROUGHPUT && profile != P3HIP_PROFILE_LATENCY) return fail(ERR_BAD_ARG, "set_thread_profile: unknown profile");
+        Context* cx;
+        int rc = get_context(&cx);
+        if (rc) return rc;
+        cx->profile = profile == P3HIP_PROFILE_THROUGHPUT ? PROFILE_THROUGHPUT : PROFILE_LATENCY;
+        return OK;
+    });
 }
-int p3hip_fib_prover_create_hash(int hash, unsigned log_n, const p3hip_fri_params_t* params, void* stream, int own_stream,
-                                 p3hip_fib_prover_t** out) {
+int p3hip_get_thread_profile(void) {
+    Context* cx;
+    if (get_context(&cx)) return -1;
+    return cx->profile == PROFILE_THROUGHPUT ? P3HIP_PROFILE_THROUGHPUT : P3HIP_PROFILE_LATENCY;
+}
+
+int p3hip_fib_prover_create_profile(int profile, int hash, int hiding, uint64_t seed, unsigned log_n, const p3hip_fri_params_t* params,
+                                    void* stream, int own_stream, p3hip_fib_prover_t** out) {
     return guarded([&]() -> int {
         if (!params || !out) return fail(ERR_BAD_ARG, "fib_prover_create: null argument");
+        if (profile != P3HIP_PROFILE_THROUGHPUT && profile != P3HIP_PROFILE_LATENCY) return fail(ERR_BAD_ARG, "fib_prover_create: unknown profile");
+        const int prof = profile == P3HIP_PROFILE_THROUGHPUT ? PROFILE_THROUGHPUT : PROFILE_LATENCY;
         Context* cx;
         int rc = get_context(&cx);
         if (rc) return rc;
@@ -490,19 +511,34 @@ int p3hip_fib_prover_create_hash(int hash, unsigned log_n, const p3hip_fri_param
         }
         std::unique_ptr<p3hip_fib_prover> p(new p3hip_fib_prover());
         FriParams fp{params->log_blowup, params->log_final_poly_len, params->num_queries, params->proof_of_work_bits};
-        p->plain.reset(new FibProver());
-        rc = p->plain->init(log_n, fp, st, own, hash);  // on failure the prover's destructor destroys the owned stream
+        // on failure the prover's destructor destroys the owned stream
+        if (hiding) {
+            p->hiding.reset(new FibHidingProver());
+            rc = p->hiding->init(log_n, fp, st, own, hash, seed, prof);
+        } else {
+            p->plain.reset(new FibProver());
+            rc = p->plain->init(log_n, fp, st, own, hash, prof);
+        }
         if (rc) return rc;
         *out = p.release();
         return OK;
     });
+}
+// a prover created on its own proves one proof at a time (what the reference does, fib_air.rs:56-72): the latency profile
+int p3hip_fib_prover_create(unsigned log_n, const p3hip_fri_params_t* params, void* stream, int own_stream,
+                            p3hip_fib_prover_t** out) {
+    return p3hip_fib_prover_create_profile(P3HIP_PROFILE_LATENCY, HASH_POSEIDON2, 0, 0, log_n, params, stream, own_stream, out);
+}
+int p3hip_fib_prover_create_hash(int hash, unsigned log_n, const p3hip_fri_params_t* params, void* stream, int own_stream,
+                                 p3hip_fib_prover_t** out) {
+    return p3hip_fib_prover_create_profile(P3HIP_PROFILE_LATENCY, hash, 0, 0, log_n, params, stream, own_stream, out);
 }
 
 int p3hip_fib_prover_prove(p3hip_fib_prover_t* prover, uint64_t a, uint64_t b, const uint8_t** proof_out,
                            size_t* proof_len) {
     return guarded([&]() -> int {
         if (!prover || !proof_out || !proof_len) return fail(ERR_BAD_ARG, "fib_prover_prove: null argument");
-        int rc = prover->hiding ? prover->hiding->prove(a, b, &prover->last) : prover->plain->prove(a, b, &prover->last);
+        int rc = prover->prove(a, b);
         if (rc) return rc;
         *proof_out = prover->last.data();
         *proof_len = prover->last.size();
@@ -514,11 +550,12 @@ int p3hip_fib_prover_prove_into(p3hip_fib_prover_t* prover, uint64_t a, uint64_t
     return guarded([&]() -> int {
         if (!prover || !out || !proof_len) return fail(ERR_BAD_ARG, "fib_prover_prove_into: null argument");
         // proofs of one prover have one length: once it is known, a buffer that cannot hold it fails BEFORE any work is queued
-        if (!prover->last.empty() && prover->last.size() > cap) {
-            *proof_len = prover->last.size();
-            return fail(ERR_BAD_ARG, "fib_prover_prove_into: the proof needs " + std::to_string(prover->last.size()) + " bytes");
+        // (the length is a field of its own, set by a proof that succeeded: `last` may be empty or stale after a failure)
+        if (prover->proof_len && prover->proof_len > cap) {
+            *proof_len = prover->proof_len;
+            return fail(ERR_BAD_ARG, "fib_prover_prove_into: the proof needs " + std::to_string(prover->proof_len) + " bytes");
         }
-        int rc = prover->hiding ? prover->hiding->prove(a, b, &prover->last) : prover->plain->prove(a, b, &prover->last);
+        int rc = prover->prove(a, b);
         if (rc) return rc;
         *proof_len = prover->last.size();
         if (prover->last.size() > cap) return fail(ERR_BAD_ARG, "fib_prover_prove_into: the proof needs " + std::to_string(prover->last.size()) + " bytes");
@@ -539,7 +576,8 @@ int p3hip_fib_prover_finish(p3hip_fib_prover_t* prover, const uint8_t** proof_ou
         if (!prover || !proof_out || !proof_len) return fail(ERR_BAD_ARG, "fib_prover_finish: null argument");
         if (!prover->plain) return fail(ERR_BAD_ARG, "fib_prover_finish: the hiding prover proves one proof at a time");
         int rc = prover->plain->finish(&prover->last);
-        if (rc) return rc;
+        if (rc) { prover->last.clear(); return rc; }
+        prover->proof_len = prover->last.size();
         *proof_out = prover->last.data();
         *proof_len = prover->last.size();
         return OK;
@@ -571,25 +609,7 @@ void p3hip_fib_prover_destroy(p3hip_fib_prover_t* prover) { delete prover; }
 
 int p3hip_fib_prover_create_hiding(int hash, unsigned log_n, const p3hip_fri_params_t* params, uint64_t seed, void* stream,
                                    int own_stream, p3hip_fib_prover_t** out) {
-    return guarded([&]() -> int {
-        if (!params || !out) return fail(ERR_BAD_ARG, "fib_prover_create_hiding: null argument");
-        Context* cx;
-        int rc = get_context(&cx);
-        if (rc) return rc;
-        hipStream_t st = (hipStream_t)stream;
-        bool own = false;
-        if (own_stream) {
-            P3_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-            own = true;
-        }
-        std::unique_ptr<p3hip_fib_prover> p(new p3hip_fib_prover());
-        FriParams fp{params->log_blowup, params->log_final_poly_len, params->num_queries, params->proof_of_work_bits};
-        p->hiding.reset(new FibHidingProver());
-        rc = p->hiding->init(log_n, fp, st, own, hash, seed);
-        if (rc) return rc;
-        *out = p.release();
-        return OK;
-    });
+    return p3hip_fib_prover_create_profile(P3HIP_PROFILE_LATENCY, hash, 1, seed, log_n, params, stream, own_stream, out);
 }
 int p3hip_verify_fib_air_hiding(int hash, const uint8_t* proof, size_t len, uint64_t a, uint64_t b, uint64_t x, unsigned log_n,
                                 const p3hip_fri_params_t* params) {
@@ -729,13 +749,14 @@ struct p3hip_fib_batch {
 
     bool hiding = false;  // provers of the reference's hiding configuration (every one seeded with `seed`, as a fresh
     uint64_t seed = 1;    // config per proof would be: fib_air.rs:50,65)
+    int profile = PROFILE_THROUGHPUT;  // several provers share the chip; a pool of ONE prover is a lone prover: latency
     void worker_main() {
         if (hiding) {
             FibHidingProver prover;
-            worker_loop(prover, [&](hipStream_t st) { return prover.init(log_n, fp, st, true, hash, seed); });
+            worker_loop(prover, [&](hipStream_t st) { return prover.init(log_n, fp, st, true, hash, seed, profile); });
         } else {
             FibProver prover;
-            worker_loop(prover, [&](hipStream_t st) { return prover.init(log_n, fp, st, true, hash); });
+            worker_loop(prover, [&](hipStream_t st) { return prover.init(log_n, fp, st, true, hash, profile); });
         }  // the prover (arena, stream) is gone before the thread's tables and scratch are freed
         release_thread_contexts();
     }
@@ -817,6 +838,7 @@ static int fib_batch_create(int hash, unsigned log_n, const p3hip_fri_params_t* 
         bt->log_n = log_n;
         bt->hash = hash;
         bt->hiding = hiding; bt->seed = seed;
+        bt->profile = n_provers > 1 ? PROFILE_THROUGHPUT : PROFILE_LATENCY;
         P3_HIP(hipGetDevice(&bt->device));
         bt->fp = FriParams{params->log_blowup, params->log_final_poly_len, params->num_queries, params->proof_of_work_bits};
         for (unsigned t = 0; t < n_provers; t++) bt->workers.emplace_back([p = bt.get()] { p->worker_main(); });

@@ -25,6 +25,13 @@ namespace p3 {
 #define P3_LATENCY_BOUND_KERNEL() ((void)0)
 #endif
 
+// Chosen when an object is CREATED (as the reference picks its backend at construction, native/src/gpu_dft.rs:85-92), never read
+// from the environment.  LATENCY: one proof at a time is what the reference does (MainActivity.kt:29-33, fib_air.rs:56-72) — forms
+// that shorten a lone proof's chain of dependent launches at the price of extra lane-instructions (quad Poseidon2 layers,
+// cooperative Keccak up to 2^12 digests, the randomization commitment on a second side stream, the single-workgroup FRI tail).
+// THROUGHPUT: several provers share the chip and VALU issue is what is short — the per-lane forms.  Results never differ.
+enum Profile : int { PROFILE_THROUGHPUT = 0, PROFILE_LATENCY = 1 };
+
 enum Status : int {
     OK = 0,
     ERR_BAD_ARG = -1,   // null pointer / non power-of-two height / bad width
@@ -70,6 +77,7 @@ struct CachedTable {  // a table built by a kernel on `built_on`; other streams 
 // the work is enqueued on, so calls issued from one thread on different streams never share an intermediate.
 struct Context {
     int device = -1;
+    int profile = PROFILE_LATENCY;  // of the free functions called on this thread (p3hip_set_thread_profile); objects carry their own
     uint32_t* tile_tw[2] = {nullptr, nullptr};  // [inverse]: reference-layout stage tables, 2^12-1 words
     double2* tile_twd[2] = {nullptr, nullptr};  // the same tables as {w, w / P} doubles of canonical values (fp64 kernels)
     std::map<std::pair<uint32_t, int>, CachedTable> root_tables;                   // (q, inverse) -> w_{2^q}^e

@@ -25,9 +25,11 @@ struct Tree {
 
 // ext_layers: optional caller-owned storage of (2*max_height - 1) * 8 words for the digest layers.
 // strides: optional words between two rows per matrix (a matrix may be a column group of a wider one); default = widths.
+// profile (common.h): how layers of 2^10 .. 2^15 digests are hashed — the latency forms (a lone tree / proof) or the per-lane
+// forms (several provers sharing the chip).  Digests are the same either way.
 int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t* heights, const size_t* widths,
                 size_t n_mats, Tree** out, uint32_t* ext_layers = nullptr, uint32_t* root_copy = nullptr,
-                int kind = HASH_POSEIDON2, const size_t* strides = nullptr);
+                int kind = HASH_POSEIDON2, const size_t* strides = nullptr, int profile = PROFILE_LATENCY);
 inline size_t mmcs_layer_words(uint64_t max_height) { return (size_t)(2 * max_height - 1) * 8; }
 int mmcs_root(hipStream_t stream, const Tree& t, uint32_t root_out[8]);
 int mmcs_open(hipStream_t stream, const Tree& t, uint64_t index, uint32_t* rows_out, uint32_t* path_out);

@@ -378,26 +378,6 @@ __global__ void poseidon2_permute_kernel(uint32_t* states, uint64_t n) {
     for (int k = 0; k < 4; k++) q[k] = make_uint4(s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]);
 }
 
-__global__ void __launch_bounds__(256) poseidon2_permute_x2_kernel(uint32_t* states, uint64_t n) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t half = (n + 1) / 2;
-    if (i >= half) return;
-    uint32_t s[16], t[16];
-    uint4* q = reinterpret_cast<uint4*>(states + i * 16);
-    uint64_t i2 = i + half < n ? i + half : i;
-    uint4* q2 = reinterpret_cast<uint4*>(states + i2 * 16);
-#pragma unroll
-    for (int k = 0; k < 4; k++) { uint4 v = q[k]; s[4 * k] = v.x; s[4 * k + 1] = v.y; s[4 * k + 2] = v.z; s[4 * k + 3] = v.w; }
-#pragma unroll
-    for (int k = 0; k < 4; k++) { uint4 v = q2[k]; t[4 * k] = v.x; t[4 * k + 1] = v.y; t[4 * k + 2] = v.z; t[4 * k + 3] = v.w; }
-    p2::permute2(s, t);
-#pragma unroll
-    for (int k = 0; k < 4; k++) q[k] = make_uint4(s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]);
-    if (i2 != i) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) q2[k] = make_uint4(t[4 * k], t[4 * k + 1], t[4 * k + 2], t[4 * k + 3]);
-    }
-}
 
 __global__ void poseidon2_permute_f64_kernel(uint32_t* states, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -450,23 +430,7 @@ int poseidon2_permute_states_variant(hipStream_t stream, uint32_t* d_states, uin
 }
 
 int poseidon2_permute_states(hipStream_t stream, uint32_t* d_states, uint64_t n) {
-    static int use_f64 = [] { const char* e = getenv("P3HIP_P2_F64"); return e ? atoi(e) : 1; }();
-    static int use_x2 = [] { const char* e = getenv("P3HIP_P2_X2"); return e ? atoi(e) : 0; }();
-    if (n && use_x2) {
-        uint64_t half = (n + 1) / 2;
-        hipLaunchKernelGGL(poseidon2_permute_x2_kernel, dim3((uint32_t)((half + 255) / 256)), dim3(256), 0, stream, d_states, n);
-        P3_HIP(hipGetLastError());
-        return OK;
-    }
-    if (n && use_f64) {
-        hipLaunchKernelGGL(poseidon2_permute_f64_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_states, n);
-        P3_HIP(hipGetLastError());
-        return OK;
-    }
-    if (!n) return OK;
-    hipLaunchKernelGGL(poseidon2_permute_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_states, n);
-    P3_HIP(hipGetLastError());
-    return OK;
+    return poseidon2_permute_states_variant(stream, d_states, n, 1);  // the fp64 form (poseidon2_f64.hip.h); variant 0 = int32 Montgomery
 }
 
 // ---- the reference's own hash configuration (native/src/fib_air.rs:28-38): Keccak-f[1600] sponge over u64 lanes ----
@@ -570,13 +534,8 @@ static uint32_t salted_rows_of(const RowSet& rs, SaltedRows<NP>* a) {
     a->stride = rs.stride[0];
     return w;
 }
-static bool leaf_salted_enabled() {  // P3HIP_LEAF_SALTED=0: the generic row-set kernel for the hiding MMCS's leaves too
-    static const bool on = [] { const char* e = getenv("P3HIP_LEAF_SALTED"); return !e || atoi(e) != 0; }();
-    return on;
-}
 // returns true when a salted-leaf kernel was launched for the tallest class
 static bool launch_keccak_leaf_salted(hipStream_t stream, const RowSet& rs, uint64_t n_rows, uint32_t* digests) {
-    if (!leaf_salted_enabled()) return false;
     const dim3 grid((uint32_t)((n_rows + 255) / 256)), block(256);
     SaltedRows<1> a1;
     SaltedRows<4> a4;
@@ -793,14 +752,6 @@ static RowSet make_rowset(const Tree& t, uint64_t h) {
     return rs;
 }
 
-static bool leaf_wide_enabled() {  // P3HIP_LEAF_WIDE=0: the one-row-per-lane kernel for wide rows too
-    static const bool on = [] { const char* e = getenv("P3HIP_LEAF_WIDE"); return !e || atoi(e) != 0; }();
-    return on;
-}
-static bool use_f64_tree() {
-    static int v = [] { const char* e = getenv("P3HIP_TREE_F64"); return e ? atoi(e) : 1; }();
-    return v != 0;
-}
 
 static bool has_height(const Tree& t, uint64_t h) {
     for (size_t m = 0; m < t.mats.size(); m++)
@@ -815,7 +766,7 @@ Tree::~Tree() {
 }
 
 int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t* heights, const size_t* widths,
-                size_t n_mats, Tree** out, uint32_t* ext_layers, uint32_t* root_copy, int kind, const size_t* strides) {
+                size_t n_mats, Tree** out, uint32_t* ext_layers, uint32_t* root_copy, int kind, const size_t* strides, int profile) {
     if (kind != HASH_POSEIDON2 && kind != HASH_KECCAK) return fail(ERR_BAD_ARG, "mmcs_commit: unknown hash configuration");
     if (!n_mats || !d_mats || !heights || !widths || !out) return fail(ERR_BAD_ARG, "mmcs_commit: null/empty argument");
     if (n_mats > 64) return fail(ERR_BAD_ARG, "mmcs_commit: at most 64 matrices per commitment");
@@ -854,36 +805,32 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
         off += len * 8;
         if (len == 1) break;
     }
-    // Layers with fewer than COOP_MAX permutations cannot fill the chip with one state per lane: they run the
-    // 16-lanes-per-state kernels (latency ~3x lower: ~3 us a level against ~8); the last digests finish inside one workgroup.
-    // P3HIP_COOP_MAX_LOG: 15 minimises a single tree's latency (a 2^20 proof: 3.3 ms against 3.6), but the 16-lane form
-    // costs ~3.4x the VALU work of a one-state-per-lane permutation, and since the small kernels run at raised wave
-    // priority (common.h) their latency no longer stretches under load: with four provers 12 is worth +5 %
-    // (557 -> 587 proofs/s; 10..12 within noise), so 12 is the default.
-    static const uint64_t COOP_MAX = [] { const char* e = getenv("P3HIP_COOP_MAX_LOG"); int v = e ? atoi(e) : 12; return (uint64_t)1 << (v < 7 ? 7 : (v > 15 ? 15 : v)); }();
-    // digests per workgroup of the 16-lane cooperative Poseidon2 levels kernel: 2^5 = four waves, five levels per launch (2^7, sixteen
-    // waves on one CU and seven levels, measured 1.5 % slower at four provers)
-    static const uint32_t COOP_CHUNK_LOG = [] { const char* e = getenv("P3HIP_COOP_CHUNK_LOG"); int v = e ? atoi(e) : 5; return (uint32_t)(v < 3 ? 3 : (v > 7 ? 7 : v)); }();
-    // One state per quad (poseidon2_q4.hip.h) for layers of COOP_MAX .. 2^P3HIP_Q4_MAX_LOG permutations: 4-7 us a launch instead of ~12 at
-    // 1.6x the lane-instructions.  A LATENCY switch, off by default: a single 2^20 proof 3.53 -> 3.33-3.38 ms with 15, but four concurrent
-    // provers LOSE 3.8 % (587 -> 565 proofs/s; 13: 565, 14: 560; without the raised wave priority: 490) — the extra lane-instructions
-    // run at priority 3 against the other provers' hash layers (profiles/r04_latency_ab.txt).  At 2^16 permutations the quad form would
-    // be four waves per SIMD and loses to the per-lane form's one even alone.
-    static const uint64_t Q4_MAX = [] { const char* e = getenv("P3HIP_Q4_MAX_LOG"); int v = e ? atoi(e) : 0; return v <= 0 ? (uint64_t)0 : (uint64_t)1 << (v > 17 ? 17 : v); }();
-    static const uint32_t Q4_PRIO = [] { const char* e = getenv("P3HIP_Q4_PRIO"); return (uint32_t)(e ? atoi(e) : 1); }();
-    // Cooperative Keccak levels for layers of <= 2^10 digests: one state per wave spends ~13x the lane-instructions of the per-lane form,
-    // and with four provers VALU is what the chip is short of (2^12: 624.6 proofs/s, 2^11: 633, 2^10: 647, 2^9: 636 in the Keccak bench;
-    // the hiding bench does not care; a single proof's latency prefers 12: +0.2 ms at 10)
-    static const uint64_t KCOOP_IN = [] { const char* e = getenv("P3HIP_KECCAK_COOP_MAX_LOG"); int v = e ? atoi(e) : 10; return v <= 0 ? (uint64_t)0 : (uint64_t)1 << (v > 15 ? 15 : v); }();
+    // ---- small-layer policy, by PROFILE (common.h; round 5: was a set of process-global environment switches) ----
+    // Layers with fewer than 2^12 permutations cannot fill the chip with one state per lane: they run the 16-lanes-per-state
+    // kernels (latency ~3x lower: ~3 us a level against ~8), 2^5 digests per workgroup = four waves, five levels per launch; the
+    // last digests finish inside one workgroup.  (Below 2^15 instead of 2^12: a lone 2^20 proof 3.3 against 3.6 ms, but the
+    // 16-lane form costs ~3.4x the VALU work and four provers lose 5 %; the quad form below took that range over.)
+    constexpr uint64_t COOP_MAX = 1ull << 12;
+    constexpr uint32_t COOP_CHUNK_LOG = 5;
+    // LATENCY profile: one Poseidon2 state per DPP quad (poseidon2_q4.hip.h) for layers of 2^12 .. 2^15 permutations: 4-7 us a
+    // launch instead of ~12 at 1.6x the lane-instructions: a lone 2^20 proof 3.53 -> 3.33-3.38 ms.  THROUGHPUT profile: off — four
+    // concurrent provers LOSE 3.8 % with it (587 -> 565 proofs/s): the extra lane-instructions run at raised priority against the
+    // other provers' hash layers (profiles/r04_latency_ab.txt).  At 2^16 permutations the quad form loses even alone.
+    const uint64_t Q4_MAX = profile == PROFILE_LATENCY ? (1ull << 15) : 0;
+    constexpr uint32_t Q4_PRIO = 1;
+    // Cooperative Keccak levels (one state per wave, ~13x the lane-instructions of the per-lane form): layers of <= 2^10 digests
+    // under the THROUGHPUT profile (four provers: 2^12: 624.6 proofs/s, 2^11: 633, 2^10: 647, 2^9: 636), <= 2^12 under the LATENCY
+    // profile (a lone proof: -0.2 ms); 2^4 digests per workgroup
+    const uint64_t KCOOP_IN = profile == PROFILE_LATENCY ? (1ull << 12) : (1ull << 10);
+    constexpr uint32_t KCOOP_CHUNK_LOG = 4;
     // one-state-per-lane levels kernel: digests per workgroup.  A level costs one permutation's issue time (~9 us) per
     // wave a SIMD holds, so ONE wave per workgroup (128 digests) spreads a layer of <= 2^15 digests over the whole chip;
     // 2048 (sixteen waves on one CU) was 25 us per level
-    static const uint64_t KLANE_CHUNK = [] { const char* e = getenv("P3HIP_KECCAK_LANE_CHUNK_LOG"); int v = e ? atoi(e) : 7; return (uint64_t)1 << (v < 7 ? 7 : (v > 11 ? 11 : v)); }();
-    static const uint32_t KCOOP_CHUNK_LOG = [] { const char* e = getenv("P3HIP_KECCAK_COOP_CHUNK_LOG"); int v = e ? atoi(e) : 4; return (uint32_t)(v < 1 ? 1 : (v > 5 ? 5 : v)); }();
+    constexpr uint64_t KLANE_CHUNK = 1ull << 7;
     if (kind == HASH_KECCAK) {
         // one state per lane for the large layers, the lane-cooperative form (shuffles inside a half-wave) for the small ones
         RowSet rs0 = make_rowset(*t, maxh);
-        if (rs0.count == 1 && rs0.width[0] >= 68 && rs0.stride[0] == rs0.width[0] && leaf_wide_enabled())
+        if (rs0.count == 1 && rs0.width[0] >= 68 && rs0.stride[0] == rs0.width[0])
             hipLaunchKernelGGL(keccak_leaf_wide_kernel, dim3((uint32_t)((maxh + 255) / 256)), dim3(256), 0, stream, rs0.ptr[0], rs0.width[0], maxh,
                                t->layers);
         else if (!launch_keccak_leaf_salted(stream, rs0, maxh, t->layers))
@@ -927,16 +874,16 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
         if (dense1 && maxh < COOP_MAX && maxh * 16 <= 0x7fffffffull) {
             hipLaunchKernelGGL(leaf_coop_kernel, dim3((uint32_t)((maxh * 16 + 255) / 256)), dim3(256), 0, stream, rs.ptr[0],
                                rs.width[0], (uint32_t)maxh, t->layers);
-        } else if (dense1 && use_f64_tree() && maxh <= Q4_MAX && rs.width[0] <= 64 && (reinterpret_cast<uintptr_t>(t->layers) & 15u) == 0) {
+        } else if (dense1 && maxh <= Q4_MAX && rs.width[0] <= 64 && (reinterpret_cast<uintptr_t>(t->layers) & 15u) == 0) {
             hipLaunchKernelGGL(leaf_hash_q4_kernel, dim3((uint32_t)((maxh * 4 + 255) / 256)), dim3(256), 0, stream, rs.ptr[0], rs.width[0], maxh,
                                t->layers, Q4_PRIO);
-        } else if (dense1 && use_f64_tree() && rs.width[0] >= 64 && leaf_wide_enabled()) {
+        } else if (dense1 && rs.width[0] >= 64) {
             hipLaunchKernelGGL(leaf_hash_f64_wide_kernel, dim3((uint32_t)((maxh + 255) / 256)), dim3(256), 0, stream, rs.ptr[0],
                                rs.width[0], maxh, t->layers);
-        } else if (dense1 && use_f64_tree()) {
+        } else if (dense1) {
             hipLaunchKernelGGL(leaf_hash_f64_kernel, dim3((uint32_t)((maxh + 255) / 256)), dim3(256), 0, stream, rs.ptr[0],
                                rs.width[0], maxh, t->layers);
-        } else if (use_f64_tree() && (maxh >= COOP_MAX || (rs.count == 1 && !dense1))) {
+        } else if ((maxh >= COOP_MAX || (rs.count == 1 && !dense1))) {
             hipLaunchKernelGGL(leaf_hash_f64_rowset_kernel, dim3((uint32_t)((maxh + 255) / 256)), dim3(256), 0, stream, rs, maxh, t->layers);
         } else {
             hipLaunchKernelGGL(leaf_hash_kernel, dim3((uint32_t)((maxh + 255) / 256)), dim3(256), 0, stream, rs, maxh, t->layers);
@@ -964,10 +911,10 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
             l += levels;
             continue;
         }
-        if (!inject && use_f64_tree() && len <= Q4_MAX) {
+        if (!inject && len <= Q4_MAX) {
             hipLaunchKernelGGL(compress_layer_q4_kernel, dim3((uint32_t)((len * 4 + 255) / 256)), dim3(256), 0, stream,
                                t->layers + t->layer_off[l - 1], t->layers + t->layer_off[l], len, Q4_PRIO);
-        } else if (!inject && use_f64_tree()) {
+        } else if (!inject) {
             hipLaunchKernelGGL(compress_layer_f64_kernel, dim3((uint32_t)((len + 255) / 256)), dim3(256), 0, stream,
                                t->layers + t->layer_off[l - 1], t->layers + t->layer_off[l], len);
         } else {

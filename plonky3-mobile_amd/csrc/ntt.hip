@@ -278,7 +278,7 @@ __device__ __forceinline__ bool colside_addr(const PassArgs& a, uint32_t kind, u
 //   3 DIF non-last (INPLACE, post-twiddle)       4 DIF last, bit-reversed out (GROUP -> GROUP)
 //   5 DIF last, natural out (GROUP_REV -> STRIDED)
 template <int LOG_RUN, int LOG_R, int MODE>
-__global__ void __launch_bounds__(LOG_RUN == 3 ? 256 : 1024) ntt_pass_kernel(PassArgs a) {
+__global__ void __launch_bounds__(1024) ntt_pass_kernel(PassArgs a) {
     const uint32_t load_kind = MODE == 0 ? a.load_kind : (MODE == 1 ? (uint32_t)SIDE_STRIDED : (MODE == 2 || MODE == 3) ? (uint32_t)SIDE_INPLACE : MODE == 4 ? (uint32_t)SIDE_GROUP : (uint32_t)SIDE_GROUP_REV);
     const uint32_t store_kind = MODE == 0 ? a.store_kind : (MODE == 1 ? (uint32_t)SIDE_GROUP_REV : (MODE == 2 || MODE == 3) ? (uint32_t)SIDE_INPLACE : MODE == 4 ? (uint32_t)SIDE_GROUP : (uint32_t)SIDE_STRIDED);
     const uint32_t dif = MODE == 0 ? a.dif : (MODE >= 3 ? 1u : 0u);
@@ -480,15 +480,8 @@ int bit_reverse_rows(hipStream_t stream, const uint32_t* src, uint32_t* dst, uin
 // ---------------------------------------------------------------------------------------------
 namespace {
 
-// Largest tile (log2 points per pass).  Tunable for experiments: P3HIP_NTT_BMAX=7..11.
-uint32_t b_max() {
-    static uint32_t v = [] {
-        const char* e = getenv("P3HIP_NTT_BMAX");
-        uint32_t x = e ? (uint32_t)atoi(e) : 9u;  // measured best on MI355X: 2^20/2^21 -> three 7-stage passes
-        return x < 4 ? 4u : (x > 11 ? 11u : x);
-    }();
-    return v;
-}
+// Largest tile (log2 points per pass) of the general plans: 9, measured best on MI355X (2^20 / 2^21 rows -> three 7-stage passes).
+constexpr uint32_t b_max() { return 9u; }
 
 // Digits, lowest position digit first.
 std::vector<uint32_t> split_digits(uint32_t n) {
@@ -515,7 +508,7 @@ int launch_pass_m(Context& cx, hipStream_t stream, const PassArgs& a, uint32_t b
     uint32_t npts = 1u << a.b;
     uint32_t threads = (npts * RUN) >> LOG_R;
     if (threads < 64) threads = 64;
-    if (threads > (LOG_RUN == 3 ? 256u : 1024u)) return fail(ERR_INTERNAL, "ntt: tile needs more threads than the kernel's launch bound");
+    if (threads > 1024u) return fail(ERR_INTERNAL, "ntt: tile needs more threads than the kernel's launch bound");
     size_t lds = (size_t)npts * (RUN + 1) * 4 + (size_t)npts * 4;
     auto kern = ntt_pass_kernel<LOG_RUN, LOG_R, MODE>;
     { int rc = cx.ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024); if (rc) return rc; }
@@ -603,9 +596,7 @@ int launch_fast(Context& cx, hipStream_t stream, const PassArgs& a, uint32_t blo
 
 int launch_pass(Context& cx, hipStream_t stream, PassArgs& a) {
     // geometry
-    static int force_run = [] { const char* e = getenv("P3HIP_NTT_LOGRUN"); return e ? atoi(e) : 0; }();
     uint32_t log_run = a.b >= 11 ? 4 : 5;
-    if (force_run == 3 && a.W <= 8 && a.b >= 8 && a.b <= 10) log_run = 3;  // narrow matrices: small tiles, many workgroups
     uint32_t RUN = 1u << log_run;
     a.wshift = is_pow2(a.W) ? log2u(a.W) : 0xffffffffu;
     uint64_t blocks;
@@ -628,8 +619,7 @@ int launch_pass(Context& cx, hipStream_t stream, PassArgs& a) {
     }
     if (blocks > 0x7fffffffull) return fail(ERR_BAD_ARG, "ntt: matrix too large for one launch");
     uint32_t nb = (uint32_t)blocks;
-    static int use_fast = [] { const char* e = getenv("P3HIP_NTT_FAST"); return e ? atoi(e) : 1; }();
-    if (use_fast && log_run == 5 && a.b >= 6 && a.b <= 10) {
+    if (log_run == 5 && a.b >= 6 && a.b <= 10) {
         int mode = pass_mode(a);
         if (mode == 2 || mode == 3) {
             const uint32_t rows_per_lane = a.b >= 9 ? 32 : 16;
@@ -641,7 +631,6 @@ int launch_pass(Context& cx, hipStream_t stream, PassArgs& a) {
         if ((mode == 1 || (mode == 4 && !a.has_sc)) && (a.W >= 32 || a.wshift != 0xffffffffu)) return launch_fast(cx, stream, a, nb, mode);
     }
 general:
-    if (log_run == 3) return launch_pass_t<3, 5, false>(cx, stream, a, nb);
     if (log_run == 4) return launch_pass_t<4, 5, false>(cx, stream, a, nb);
     uint32_t log_r = a.b >= 10 ? 5 : (a.b >= 4 ? 4 : a.b);
     switch (log_r) {
@@ -733,8 +722,7 @@ int launch_fused_mid_t(hipStream_t stream, const PassArgs& a, uint32_t blocks) {
 // coset LDE with the middle passes fused.  Returns 1 when the shape is not covered.
 int lde_fused(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* dst, uint32_t n, uint32_t added, uint32_t W,
               uint32_t shift, bool bit_reversed_out) {
-    static int enabled = [] { const char* e = getenv("P3HIP_NTT_FUSED"); return e ? atoi(e) : 1; }();
-    if (!enabled || !bit_reversed_out || added < 1 || added > 2) return 1;
+    if (!bit_reversed_out || added < 1 || added > 2) return 1;
     const uint32_t m = n + added;
     // forward digits (lowest first) e1, e2, e3 with e3 = top; inverse digits e1, e2, e3 - added
     std::vector<uint32_t> fd = split_digits(m);
@@ -821,14 +809,12 @@ template <int B, int LQ, int VW, int K>
 int launch_narrow_t(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t blocks, uint32_t grid_y = 1) {
     // padded tile (17 rows per 16 points; the middle kernel alternates two below 1024 threads) + stage-table prefixes
     constexpr size_t tile_bytes = ((size_t)4 * VW * narrow::lds_rows(B)) << LQ;
-    // the middle kernel of 512-thread pair tiles runs column-sequentially (one pair tile, two workgroups per CU)
-    constexpr bool SEQ = K == 2 && VW == 2 && B - 4 + LQ == 9 && NARROW_MID_SEQ;
-    constexpr size_t n_tiles = K == 2 ? ((SEQ || B - 4 + LQ >= 10) ? 1 : NARROW_MID_TILES) : (B >= 11 ? 1 : NARROW_EDGE_TILES);
+    constexpr size_t n_tiles = K == 2 ? (B - 4 + LQ >= 10 ? 1 : NARROW_MID_TILES) : (B >= 11 ? 1 : NARROW_EDGE_TILES);
     constexpr size_t lds = tile_bytes * n_tiles + ((size_t)4 << (B - 4)) * (K == 2 ? 2 : 1);
     static_assert(lds <= 160 * 1024, "narrow tile does not fit the LDS");
     void (*kern)(NarrowArgs);
     if constexpr (K == 1) kern = narrow_inv1_kernel<B, LQ, VW>;
-    else if constexpr (K == 2) kern = narrow_mid_kernel<B, LQ, VW, SEQ>;
+    else if constexpr (K == 2) kern = narrow_mid_kernel<B, LQ, VW>;
     else kern = narrow_fwd2_kernel<B, LQ, VW>;
     if constexpr (lds > 64 * 1024) {
         int rc = cx.ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds);
@@ -838,35 +824,36 @@ int launch_narrow_t(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32
     P3_HIP(hipGetLastError());
     return OK;
 }
-// Geometry per digit size: column pairs per lane (VW = 2) or single columns (VW = 1: twice the waves; P3HIP_NTT_NARROW_VW).
+// Geometry per digit size: column pairs per lane (VW = 2) or single columns (VW = 1: twice the waves).
 // Tile rows are 32 bytes (LQ = 2 for pairs, 3 for single words), 16 bytes for 12-stage digits (64 KB tiles, <= 1024 threads).
 constexpr int narrow_lq(int b, int vw) { return (b == 12 ? 1 : 2) + (vw == 1 ? 1 : 0); }
+// INTEGER butterflies: digits of 10..12 stages, i.e. heights from 2^20 on, where they win (profiles/r04_lde_f64_vs_int.txt); single
+// columns only where lde_narrow picks them (the 2^20 middle kernel).  Smaller digits run the fp64 kernels below; round 5 retired
+// the integer instantiations for 8- and 9-stage digits of narrow matrices (3-8 % slower there, profiles/r03_lde_f64_vs_int.txt).
 template <int K, int VW>
 int launch_narrow_v(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t b, uint32_t blocks, uint32_t gy) {
-    switch (b) {
-        case 8: return launch_narrow_t<8, narrow_lq(8, VW), VW, K>(cx, stream, a, blocks, gy);
-        case 9: return launch_narrow_t<9, narrow_lq(9, VW), VW, K>(cx, stream, a, blocks, gy);
-        case 10: return launch_narrow_t<10, narrow_lq(10, VW), VW, K>(cx, stream, a, blocks, gy);
-        case 11: return launch_narrow_t<11, narrow_lq(11, VW), VW, K>(cx, stream, a, blocks, gy);
-        case 12: return launch_narrow_t<12, narrow_lq(12, VW), VW, K>(cx, stream, a, blocks, gy);
-        default: return fail(ERR_INTERNAL, "lde_narrow: digit out of range");
+    if (b == 10) return launch_narrow_t<10, narrow_lq(10, VW), VW, K>(cx, stream, a, blocks, gy);
+    if constexpr (VW == 2) {
+        if (b == 11) return launch_narrow_t<11, narrow_lq(11, 2), 2, K>(cx, stream, a, blocks, gy);
+        if (b == 12) return launch_narrow_t<12, narrow_lq(12, 2), 2, K>(cx, stream, a, blocks, gy);
     }
+    return fail(ERR_INTERNAL, "lde_narrow: no integer kernel for this digit / lane vector");
 }
 template <int K>
 int launch_narrow(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t b, uint32_t blocks, int vw, uint32_t gy = 1) {
     return vw == 1 ? launch_narrow_v<K, 1>(cx, stream, a, b, blocks, gy) : launch_narrow_v<K, 2>(cx, stream, a, b, blocks, gy);
 }
 
-// fp64 forms (ntt_narrow_f64.hip.h).  NT = 2 LDS tiles (one barrier per hand-over) where they fit and the grid gives a CU
-// one workgroup anyway; otherwise one tile, so that two workgroups can share a CU.
-template <int B, int LQ, int VW, int K, int NT, bool XW>
+// fp64 forms (ntt_narrow_f64.hip.h): digits of 8..10 stages (heights up to 2^19, and 2^20 x 2).  NT = 2 LDS tiles (one barrier per
+// hand-over) where they fit and the grid gives a CU one workgroup anyway; otherwise one tile, so that two workgroups can share a CU.
+template <int B, int LQ, int VW, int K, int NT>
 int launch_narrow64_nt(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t blocks, uint32_t grid_y) {
-    constexpr size_t lds = narrow64::lds_bytes<B, LQ, VW, NT, XW>(K == 2 ? 2 : 1);
+    constexpr size_t lds = narrow64::lds_bytes<B, LQ, VW, NT>(K == 2 ? 2 : 1);
     static_assert(lds <= 160 * 1024, "fp64 narrow tile does not fit the LDS");
     void (*kern)(NarrowArgs);
-    if constexpr (K == 1) kern = narrow64_inv1_kernel<B, LQ, VW, NT, XW>;
-    else if constexpr (K == 2) kern = narrow64_mid_kernel<B, LQ, VW, NT, (VW == 2), XW>;
-    else kern = narrow64_fwd2_kernel<B, LQ, VW, NT, XW>;
+    if constexpr (K == 1) kern = narrow64_inv1_kernel<B, LQ, VW, NT>;
+    else if constexpr (K == 2) kern = narrow64_mid_kernel<B, LQ, VW, NT, (VW == 2)>;
+    else kern = narrow64_fwd2_kernel<B, LQ, VW, NT>;
     if constexpr (lds > 64 * 1024) {
         int rc = cx.ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds);
         if (rc) return rc;
@@ -875,24 +862,17 @@ int launch_narrow64_nt(Context& cx, hipStream_t stream, const NarrowArgs& a, uin
     P3_HIP(hipGetLastError());
     return OK;
 }
-// XW: hand-overs on words (tiles of the integer kernels' size) instead of doubles
-template <int B, int LQ, int VW, int K, bool XW>
-int launch_narrow64_x(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t blocks, uint32_t grid_y) {
-    constexpr bool fits2 = narrow64::lds_bytes<B, LQ, VW, 2, XW>(K == 2 ? 2 : 1) <= 160 * 1024;
-    static int nt_env = [] { const char* e = getenv("P3HIP_NTT_NARROW_F64_TILES"); return e ? atoi(e) : 0; }();
-    if constexpr (fits2) {
-        const bool two = nt_env ? nt_env == 2 : (size_t)blocks * grid_y <= 256 || narrow64::lds_bytes<B, LQ, VW, 2, XW>(K == 2 ? 2 : 1) <= 80 * 1024;
-        if (two) return launch_narrow64_nt<B, LQ, VW, K, 2, XW>(cx, stream, a, blocks, grid_y);
-    }
-    return launch_narrow64_nt<B, LQ, VW, K, 1, XW>(cx, stream, a, blocks, grid_y);
-}
 template <int B, int LQ, int VW, int K>
 int launch_narrow64_t(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t blocks, uint32_t grid_y) {
-    return a.f64_words ? launch_narrow64_x<B, LQ, VW, K, true>(cx, stream, a, blocks, grid_y)
-                       : launch_narrow64_x<B, LQ, VW, K, false>(cx, stream, a, blocks, grid_y);
+    constexpr bool fits2 = narrow64::lds_bytes<B, LQ, VW, 2>(K == 2 ? 2 : 1) <= 160 * 1024;
+    if constexpr (fits2) {
+        const bool two = (size_t)blocks * grid_y <= 256 || narrow64::lds_bytes<B, LQ, VW, 2>(K == 2 ? 2 : 1) <= 80 * 1024;
+        if (two) return launch_narrow64_nt<B, LQ, VW, K, 2>(cx, stream, a, blocks, grid_y);
+    }
+    return launch_narrow64_nt<B, LQ, VW, K, 1>(cx, stream, a, blocks, grid_y);
 }
 // 1024-thread workgroups (128 VGPRs per lane) are left to the integer kernels: K2 at single columns from 11 stages on
-constexpr bool narrow64_has(int b, int vw, int k) { return b - 4 + narrow_lq(b, vw) <= (k == 2 ? 9 : 10); }
+constexpr bool narrow64_has(int b, int vw, int k) { return b <= 10 && b - 4 + narrow_lq(b, vw) <= (k == 2 ? 9 : 10); }
 template <int K, int VW>
 int launch_narrow64_v(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t b, uint32_t blocks, uint32_t gy) {
 #define P3_N64_CASE(BB)                                                                                          \
@@ -900,7 +880,7 @@ int launch_narrow64_v(Context& cx, hipStream_t stream, const NarrowArgs& a, uint
         if constexpr (narrow64_has(BB, VW, K)) return launch_narrow64_t<BB, narrow_lq(BB, VW), VW, K>(cx, stream, a, blocks, gy); \
         else return fail(ERR_INTERNAL, "lde_narrow: fp64 shape not instantiated");
     switch (b) {
-        P3_N64_CASE(8) P3_N64_CASE(9) P3_N64_CASE(10) P3_N64_CASE(11) P3_N64_CASE(12)
+        P3_N64_CASE(8) P3_N64_CASE(9) P3_N64_CASE(10)
         default: return fail(ERR_INTERNAL, "lde_narrow: digit out of range");
     }
 #undef P3_N64_CASE
@@ -915,11 +895,11 @@ int launch_narrow64(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32
 // of 2^8 rows x 32 words, i.e. 128-byte row segments (the slots of a row group are its words in memory order, so a tile may
 // straddle rows).  Instantiated for 8- and 9-stage digits: 2^16 rows (BASELINE configs[4], 2^16 x 2633), 2^17 and 2^18 rows
 // (a 10-stage digit would need 2048 threads at this tile width).
+// Integer butterflies (2^16 x 2633: 2143 us against 2287 us with the fp64 form, which round 5 retired for this shape).
 template <int K>
-int launch_narrow_wide(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t b, uint32_t blocks, uint32_t gy, bool f64) {
-    if (b == 9) return launch_narrow_t<9, 5, 1, K>(cx, stream, a, blocks, gy);  // 2^17 / 2^18 rows: 1024-thread tiles, integer only
+int launch_narrow_wide(Context& cx, hipStream_t stream, const NarrowArgs& a, uint32_t b, uint32_t blocks, uint32_t gy) {
+    if (b == 9) return launch_narrow_t<9, 5, 1, K>(cx, stream, a, blocks, gy);  // 2^17 / 2^18 rows: 1024-thread tiles
     if (b != 8) return fail(ERR_INTERNAL, "lde_narrow: wide digit out of range");
-    if (f64) return launch_narrow64_t<8, 5, 1, K>(cx, stream, a, blocks, gy);
     return launch_narrow_t<8, 5, 1, K>(cx, stream, a, blocks, gy);
 }
 
@@ -927,45 +907,34 @@ int launch_narrow_wide(Context& cx, hipStream_t stream, const NarrowArgs& a, uin
 // K1 and the inverse half of K2 are skipped (two launches; the hiding prover's blinded quotient chunks arrive that way).
 int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* dst, uint32_t n, uint32_t added, uint32_t W,
                uint32_t shift, bool bit_reversed_out, bool from_coeffs = false) {
-    static int enabled = [] { const char* e = getenv("P3HIP_NTT_NARROW"); return e ? atoi(e) : 1; }();
-    static uint32_t n_min = [] { const char* e = getenv("P3HIP_NTT_NARROW_MIN"); return e ? (uint32_t)atoi(e) : 16u; }();
-    if (!enabled || !bit_reversed_out || added < 1 || added > 3) return 1;
-    static uint32_t w_max = [] { const char* e = getenv("P3HIP_NTT_NARROW_WMAX"); return e ? (uint32_t)atoi(e) : 16u; }();
+    if (!bit_reversed_out || added < 1 || added > 3) return 1;
     // 32-byte row segments per tile: faster than the general plans up to W = 16 (1.3-2.1x), level from W = 32 on
     // W = 6 (the hiding prover's randomized trace, fib_air.rs:65: 2 columns + 4 random codewords): three column pairs per row
-    static int wide_on = [] { const char* e = getenv("P3HIP_NTT_NARROW_WIDE"); return e ? atoi(e) : 1; }();
+    constexpr uint32_t w_max = 16;
     // 128-byte tile rows, single columns: any width whose byte offsets stay below 2^32 (the kernels index in u32: K1's
     // transposed store reaches rows * W * 4 bytes of the coefficient matrix, K2 / K3 the LDE's (rows << added) * W * 4)
-    const bool wide = W > w_max && wide_on && n >= 16 && n <= 18 && W >= 64 && (((uint64_t)W << (n + added + 2)) < (1ull << 32));
+    const bool wide = W > w_max && n >= 16 && n <= 18 && W >= 64 && (((uint64_t)W << (n + added + 2)) < (1ull << 32));
     if (!wide && (W < 2 || W > w_max || !(is_pow2(W) || W == 6))) return 1;
-    if (n < n_min || n < 16 || n > 24) return 1;
+    if (n < 16 || n > 24) return 1;
     if (!wide && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 7u)) return 1;  // 8-byte accesses
     const uint32_t n1 = (n + 1) / 2, n2 = n - n1;
     const uint64_t N = 1ull << n;
     // lane vector: column pairs, or single columns where that doubles a thin grid's waves per SIMD
-    static int force_vw = [] { const char* e = getenv("P3HIP_NTT_NARROW_VW"); return e ? atoi(e) : 0; }();
     int vw[3];  // per kernel
     // measured (tools/lde_sweep.py): single columns win by 15-25 % up to 2^19 rows (1-2 waves per SIMD otherwise), only
     // for the middle kernel at 2^20 (26.5 -> 23.7 us), and lose from 2^21 on (the grid is full; twice the twiddle work)
-    for (int k = 0; k < 3; k++) vw[k] = force_vw == 1 || force_vw == 2 ? force_vw : (n <= 19 || (n == 20 && k == 1) ? 1 : 2);
+    for (int k = 0; k < 3; k++) vw[k] = (n <= 19 || (n == 20 && k == 1)) ? 1 : 2;
     if (wide) vw[0] = vw[1] = vw[2] = 1;
-    // experiment (P3HIP_NTT_NARROW_K3_LQ1=1): K3 with 2-row tiles at 10-stage digits — twice the workgroups, half the waves each
-    static int k3_lq1_env = [] { const char* e = getenv("P3HIP_NTT_NARROW_K3_LQ1"); return e ? atoi(e) : 0; }();
-    const bool k3_lq1 = k3_lq1_env && !wide && n1 == 10 && vw[2] == 2 && W == 2;
-    auto lq_of = [&](int k, uint32_t b) -> uint32_t { return wide ? 5u : (k == 2 && k3_lq1) ? 1u : (uint32_t)narrow_lq((int)b, vw[k]); };
+    auto lq_of = [&](int k, uint32_t b) -> uint32_t { return wide ? 5u : (uint32_t)narrow_lq((int)b, vw[k]); };
     int rc = cx.ws(stream, 1).reserve(N * W * 4);
     if (rc) return rc;
     uint32_t* T = cx.ws(stream, 1).as<uint32_t>();
     NarrowArgs a{};
-    static int use_blocked = [] { const char* e = getenv("P3HIP_NTT_NARROW_BLOCKED"); return e ? atoi(e) : 1; }();
-    static int use_handover = [] { const char* e = getenv("P3HIP_NTT_NARROW_HANDOVER"); return e ? atoi(e) : 0; }();
-    // blocked intermediates need tiles of 4 rows in all three kernels (32-byte tile rows: digits below 12 stages)
-    // 12-stage digits have 2-row tiles: K3 then owns half of every 128-byte block and can no longer run in place, so K2 writes
-    // the blocked intermediate to a scratch of its own (P3HIP_NTT_NARROW_BLOCKED12=0: row-major intermediates as in round 2)
-    static int use_blocked12 = [] { const char* e = getenv("P3HIP_NTT_NARROW_BLOCKED12"); return e ? atoi(e) : 1; }();
-    const bool twelve = n1 >= 12 || n2 >= 12;
-    a.blocked = use_blocked && !NARROW_MID_SEQ && W == 2 && !from_coeffs && (!twelve || use_blocked12);
-    bool k3_out_of_place = a.blocked && (n1 >= 12 || k3_lq1);
+    // blocked intermediates (W = 2) need tiles of 4 rows in all three kernels (32-byte tile rows: digits below 12 stages); 12-stage
+    // digits have 2-row tiles: K3 then owns half of every 128-byte block and can no longer run in place, so K2 writes the blocked
+    // intermediate to a scratch of its own
+    a.blocked = W == 2 && !from_coeffs;
+    bool k3_out_of_place = a.blocked && n1 >= 12;
     uint32_t* mid = dst;  // K2's output = K3's input
     if (k3_out_of_place) {
         // slot 4 belongs to this function alone: slots 2 / 3 are the host-pointer entry points' staging buffers (c_api.hip
@@ -976,13 +945,9 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
         // K3 must never read the buffer its partner tiles write: if a caller's dst overlaps the scratch all the same, take
         // the row-major intermediates (K3 in place, no half-owned blocks)
         const uintptr_t m0 = reinterpret_cast<uintptr_t>(mid), d0 = reinterpret_cast<uintptr_t>(dst);
-        if (m0 < d0 + mid_bytes && d0 < m0 + mid_bytes) {
-            if (k3_lq1) return fail(ERR_INTERNAL, "lde_narrow: K3 scratch overlaps dst");
-            a.blocked = 0; k3_out_of_place = false; mid = dst;
-        }
+        if (m0 < d0 + mid_bytes && d0 < m0 + mid_bytes) { a.blocked = 0; k3_out_of_place = false; mid = dst; }
     }
     a.from_coeffs = from_coeffs;
-    a.mid_handover = use_handover;
     a.n = n; a.n1 = n1; a.n2 = n2; a.W = W; a.added = added;
     TwoLevelTable ti, tf;
     if ((rc = cx.get_root_table(stream, n, true, &ti))) return rc;
@@ -1002,49 +967,16 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     a.src = src; a.dst = T;
     a.stage_tw = cx.tile_tw[1];
     a.tw_lo = ti.lo; a.tw_hi = ti.hi; a.tw_T = ti.T;
-    // fp64 butterflies (6 instructions instead of 12, ntt_narrow_f64.hip.h).  Measured (profiles/r03_lde_f64_vs_int.txt): the
-    // VALU instructions per wave drop by a third, but the exchanges move doubles, so the unit gains only 3-8 % up to 2^19 rows
-    // and at 2^20 x 2, and LOSES from 2^21 rows on, where twice the LDS per workgroup halves the waves per SIMD.  Default:
-    // fp64 where it wins; P3HIP_NTT_NARROW_F64 = 0 keeps the integer kernels, 1..7 is a bit mask (1 = K1, 2 = K2, 4 = K3).
-    static int f64_env = [] { const char* e = getenv("P3HIP_NTT_NARROW_F64"); return e ? atoi(e) : -1; }();
-    const int f64_mask = f64_env >= 0 ? f64_env : ((!wide && (n <= 19 || (n == 20 && W == 2))) ? 7 : 0);  // wide: 2143 us integer, 2287 us fp64
-    auto f64 = [&](int k, uint32_t b) {
-        if (!((f64_mask >> k) & 1) || (wide && b != 8)) return false;
-        return b - 4 + lq_of(k, b) <= (k == 1 ? 9u : 10u);
-    };
-    // fp64 kernels: hand-overs as doubles, or as words (P3HIP_NTT_NARROW_F64_XW=1; tiles of the integer kernels' size, five more
-    // instructions per element and hand-over)
-    static int xw_env = [] { const char* e = getenv("P3HIP_NTT_NARROW_F64_XW"); return e ? atoi(e) : -1; }();
-    a.f64_words = xw_env >= 0 ? (uint32_t)xw_env : 0u;
+    // Arithmetic per shape, from measurement (profiles/r03_lde_f64_vs_int.txt, r04_lde_f64_vs_int.txt): fp64 butterflies (6
+    // instructions instead of 10, ntt_narrow_f64.hip.h) gain 3-8 % up to 2^19 rows and at 2^20 x 2, and LOSE from 2^21 rows on,
+    // where twice the LDS per workgroup halves the waves per SIMD; wide matrices: 2143 us integer, 2287 us fp64.
+    const bool f64 = !wide && (n <= 19 || (n == 20 && W == 2));
     a.stage_twd = cx.tile_twd[1];
     a.neg_pm1 = -2013265920.0; a.pinv = 1.0 / 2013265921.0; a.fbias = -0.5 + 1.0 / 8589934592.0;
     uint32_t tiles = geometry(0, n1, 1ull << n2);
-#if NARROW_STAMPS
-    // diagnostic build: P3HIP_NTT_STAMPS=<file> appends K1's per-workgroup phase stamps (32 u64 each) after every call
-    static const char* stamp_path = getenv("P3HIP_NTT_STAMPS");
-    if (stamp_path) {
-        if ((rc = cx.ws(stream, 7).reserve((size_t)tiles * 32 * 8))) return rc;
-        a.stamps = cx.ws(stream, 7).as<unsigned long long>();
-        P3_HIP(hipMemsetAsync(a.stamps, 0, (size_t)tiles * 32 * 8, stream));
-    }
-#endif
     if (!from_coeffs)
-        if ((rc = wide ? launch_narrow_wide<1>(cx, stream, a, n1, tiles, 1, f64(0, n1))
-                       : f64(0, n1) ? launch_narrow64<1>(cx, stream, a, n1, tiles, vw[0]) : launch_narrow<1>(cx, stream, a, n1, tiles, vw[0]))) return rc;
-#if NARROW_STAMPS
-    if (a.stamps) {
-        std::vector<unsigned long long> h((size_t)tiles * 32);
-        P3_HIP(hipStreamSynchronize(stream));
-        P3_HIP(hipMemcpy(h.data(), a.stamps, h.size() * 8, hipMemcpyDeviceToHost));
-        if (FILE* f = fopen(stamp_path, "ab")) {
-            uint32_t hdr[4] = {n, W, added, tiles};
-            fwrite(hdr, 4, 4, f);
-            fwrite(h.data(), 8, h.size(), f);
-            fclose(f);
-        }
-        a.stamps = nullptr;
-    }
-#endif
+        if ((rc = wide ? launch_narrow_wide<1>(cx, stream, a, n1, tiles, 1)
+                       : f64 ? launch_narrow64<1>(cx, stream, a, n1, tiles, vw[0]) : launch_narrow<1>(cx, stream, a, n1, tiles, vw[0]))) return rc;
     // K2
     a.src = from_coeffs ? src : T; a.dst = mid;
     a.stage_tw = cx.tile_tw[1]; a.stage_tw_fwd = cx.tile_tw[0];
@@ -1063,17 +995,14 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     tiles = geometry(1, n2, 1ull << n1);
     // Grids that leave CUs idle (fewer workgroups than CUs): split the cosets over workgroups.  Every workgroup repeats
     // the inverse digit (more arithmetic), but idle CUs take the extra workgroups: 2^16..2^18 rows gain 5-25 %
-    // (gpurun_out sweep, profiles/r02_lde_sweep_cosplit.txt); from one workgroup per CU on the kernel is bound by its
+    // (profiles/r02_lde_sweep_cosplit.txt); from one workgroup per CU on the kernel is bound by its
     // arithmetic and a split only adds to it (2^20 x 2: 52.4 -> 55.7 us), so the split stops at 256 workgroups.
-    // P3HIP_NTT_NARROW_COSSPLIT=0 disables, =n forces 2^n-way.
-    static int cos_split = [] { const char* e = getenv("P3HIP_NTT_NARROW_COSSPLIT"); return e ? atoi(e) : -1; }();
     uint32_t split_log = 0;
-    if (cos_split < 0) { while (split_log < added && ((uint64_t)tiles << (split_log + 1)) <= 256) split_log++; }
-    else split_log = std::min<uint32_t>((uint32_t)cos_split, added);
+    while (split_log < added && ((uint64_t)tiles << (split_log + 1)) <= 256) split_log++;
     a.cos_per_block = (1u << added) >> split_log;
-    if ((rc = wide ? launch_narrow_wide<2>(cx, stream, a, n2, tiles, 1u << split_log, f64(1, n2))
-                   : f64(1, n2) ? launch_narrow64<2>(cx, stream, a, n2, tiles, vw[1], 1u << split_log)
-                                : launch_narrow<2>(cx, stream, a, n2, tiles, vw[1], 1u << split_log))) return rc;
+    if ((rc = wide ? launch_narrow_wide<2>(cx, stream, a, n2, tiles, 1u << split_log)
+                   : f64 ? launch_narrow64<2>(cx, stream, a, n2, tiles, vw[1], 1u << split_log)
+                         : launch_narrow<2>(cx, stream, a, n2, tiles, vw[1], 1u << split_log))) return rc;
     // K3
     a.src = mid; a.dst = dst;
     a.stage_tw = cx.tile_tw[0];
@@ -1081,9 +1010,8 @@ int lde_narrow(Context& cx, hipStream_t stream, const uint32_t* src, uint32_t* d
     tiles = geometry(2, n1, (1ull << added) << n2);
     a.k3_pairs = k3_out_of_place && vw[2] == 2 && tiles % 16 == 0 ? 1u : 0u;
     if (wide && tiles % 128 == 0) a.k3_pairs = 4;
-    if (wide) return launch_narrow_wide<3>(cx, stream, a, n1, tiles, 1, f64(2, n1));
-    if (k3_lq1) return f64(2, n1) ? launch_narrow64_t<10, 1, 2, 3>(cx, stream, a, tiles, 1) : launch_narrow_t<10, 1, 2, 3>(cx, stream, a, tiles, 1);
-    return f64(2, n1) ? launch_narrow64<3>(cx, stream, a, n1, tiles, vw[2]) : launch_narrow<3>(cx, stream, a, n1, tiles, vw[2]);
+    if (wide) return launch_narrow_wide<3>(cx, stream, a, n1, tiles, 1);
+    return f64 ? launch_narrow64<3>(cx, stream, a, n1, tiles, vw[2]) : launch_narrow<3>(cx, stream, a, n1, tiles, vw[2]);
 }
 
 }  // namespace

@@ -25,66 +25,15 @@
 // Included by ntt.hip (needs two_level, rev_bits, power_ladder, crev).
 #pragma once
 
-// Experiment switch: compile the 512-thread middle kernels for 4 waves per SIMD (128 VGPRs) so that two workgroups
-// share a CU.  Measured slower (the 2^24 middle pass 586 -> 898 us): the ~55 spilled registers cost more than the
-// second workgroup hides.
-#ifndef NARROW_EDGE_TILES
-#define NARROW_EDGE_TILES 2  // LDS tiles of the first and last kernel for digits below 11 stages (1 or 2; two cost a workgroup per CU from 11 stages on)
-#endif
-#ifndef NARROW_MID_TILES
-#define NARROW_MID_TILES 2  // LDS tiles of the middle kernel (1 or 2)
-#endif
-#ifndef NARROW_SKIP
-#define NARROW_SKIP 0  // experiment builds only: 1 = no butterflies / ladders (the load, LDS and store skeleton alone)
-#endif
-#ifndef NARROW_MID_SEQ
-#define NARROW_MID_SEQ 0  // experiment: column-sequential coset loop for the 512-thread pair tiles (measured 2x SLOWER:
-                          // the compiler spills ~85 registers at the 128-VGPR cap; 2^24 middle pass 549 -> 1063 us)
-#endif
-#ifndef NARROW_SKIP
-#define NARROW_SKIP 0  // experiment builds only: 1 = no butterflies / ladders (the load, LDS and store skeleton alone)
-#endif
-#ifndef NARROW_TW_SHUFFLE
-#define NARROW_TW_SHUFFLE 0  // A/B build for north_star's "wavefront-shuffle twiddle broadcast": 1 = the stage twiddles of the
-                             // rounds after the first (stages below 6: at most 32 distinct values) are held one per lane
-                             // and fetched with a wave shuffle (ds_bpermute) instead of the LDS broadcast read.  Measured
-                             // on narrow_fwd2_kernel<10,..>: profiles/r02_twiddle_shuffle_vs_lds.txt — default stays 0.
-#endif
-#ifndef NARROW_MID_SEQ_WAVES
-#define NARROW_MID_SEQ_WAVES 4
-#endif
-#ifndef NARROW_MID_SHARE_CU
-#define NARROW_MID_SHARE_CU 0
-#endif
-#ifndef NARROW_STAMPS
-#define NARROW_STAMPS 0  // diagnostic builds only (tools/_bin): wave 0 of every workgroup records s_memtime at phase boundaries
-#endif
-#if NARROW_STAMPS
-#define P3_STAMP(a, i)                                                                                           \
-    do {                                                                                                         \
-        __builtin_amdgcn_s_waitcnt(0);                                                                           \
-        if ((a).stamps && threadIdx.x == 0)                                                                      \
-            (a).stamps[((uint64_t)(blockIdx.x * gridDim.y + blockIdx.y)) * 32u + (i)] = __builtin_amdgcn_s_memtime(); \
-    } while (0)
-#define P3_STAMP_RT(a, i)                                                                                        \
-    do {                                                                                                         \
-        if ((a).stamps && threadIdx.x == 0)                                                                      \
-            (a).stamps[((uint64_t)(blockIdx.x * gridDim.y + blockIdx.y)) * 32u + (i)] = __builtin_amdgcn_s_memrealtime(); \
-    } while (0)
-// every element of v[16] must be computed before the stamp that follows (the compiler otherwise sinks the arithmetic past it)
-#define P3_PIN16(v)                                                              \
-    do {                                                                         \
-        _Pragma("unroll") for (int j__ = 0; j__ < 16; j__++) pin_value((v)[j__]); \
-    } while (0)
-#else
-#define P3_STAMP(a, i) ((void)0)
-#define P3_STAMP_RT(a, i) ((void)0)
-#define P3_PIN16(v) ((void)0)
-#endif
+// LDS tiles per kernel: two cost one barrier per hand-over instead of two (the tile written now was last read two hand-overs ago).
+// Round 5 retired the experiment builds that lived here (records in profiles/): the load / LDS / store skeleton without
+// butterflies (r03_lde_skeleton_vs_full.txt), the column-sequential middle kernel and the 128-VGPR shared-CU build (both spill:
+// 2^24 middle pass 549 -> 1063 us / 586 -> 898 us), the ds_bpermute twiddle broadcast (r02_twiddle_shuffle_vs_lds.txt: 1-4 % slower),
+// write-through / non-temporal stores (r03_store_policy_ab.txt), the phase stamps (r03_lde_k1_phase_stamps.txt) and the middle
+// kernel's extra hand-over for whole-line stores.
+constexpr uint32_t NARROW_EDGE_TILES = 2;  // first and last kernel, digits below 11 stages (two cost a workgroup per CU from 11 stages on)
+constexpr uint32_t NARROW_MID_TILES = 2;   // middle kernel (one for 1024-thread tiles)
 namespace p3 {
-__device__ __forceinline__ void pin_value(uint32_t& x) { asm volatile("" : "+v"(x)); }
-__device__ __forceinline__ void pin_value(uint2& x) { asm volatile("" : "+v"(x.x), "+v"(x.y)); }
-__device__ __forceinline__ void pin_value(double& x) { asm volatile("" : "+v"(x)); }
 
 struct NarrowArgs {
     const uint32_t* src;
@@ -107,15 +56,12 @@ struct NarrowArgs {
     uint32_t sc_T;
     uint32_t sc_phi[8];           // (shift g^j)^(N1 * 2^(n2-4))
     uint32_t xcd_remap;           // 1: tile count is a multiple of 32, spread groups of 4 adjacent tiles per XCD
-    uint32_t mid_handover;        // blocked: the middle kernel re-sorts its results through LDS to store whole lines
     uint32_t cos_per_block;       // K2: cosets one workgroup transforms (grid.y = 2^added / cos_per_block); splitting the
                                   // cosets over workgroups repeats the inverse digit but doubles a thin grid's waves
     // fp64 kernels (ntt_narrow_f64.hip.h): stage tables as {w, w / P} doubles of CANONICAL values, same layout
-    unsigned long long* stamps;   // NARROW_STAMPS builds: 32 words per workgroup
     const double2* stage_twd;
     const double2* stage_twd_fwd;
     double neg_pm1, pinv, fbias;  // -(P - 1), 1 / P, -1/2 + 2^-33: uniform operands of the fp64 product / floor reduction
-    uint32_t f64_words;           // fp64 kernels: host-side choice of the hand-over form (doubles / words), not read by kernels
     uint32_t k3_pairs;            // K3: log2 of the consecutive tiles dealt to one XCD.  1 with 2-row tiles over blocked input (partner tiles =
                                   // the two halves of every 128-byte block; K3 then reads a.src out of place: in place the partner's half
                                   // would be overwritten); 4 for wide matrices (neighbours in a row complete each other's lines)
@@ -168,24 +114,17 @@ constexpr uint32_t lds_rows(int B) { return (1u << B) + (1u << (B - 4)); }
 // (a, b) -> (a + b, (a - b) * w_{2^(u+1)}^(pt mod 2^u))   [stage semantics of backend_vulkan.rs:881-942, DIF form]
 template <int A, int UHI, int ULO, class V>
 __device__ __forceinline__ void stage_block(V (&v)[16], const uint32_t* __restrict__ tw, uint32_t t) {
-    if (NARROW_SKIP) return;
     const uint32_t tlo = t & ((1u << A) - 1u);
 #pragma unroll
     for (int u = UHI - 1; u >= ULO; --u) {
         const int d = u - A;
         uint32_t w[8];
         if (u > 0) {
-            if (NARROW_TW_SHUFFLE && u <= 6) {
-                // one table entry per lane (2^u <= 64 of them), handed to the lanes that need it by a wave shuffle
-                const uint32_t mine = tw[(1u << u) - 1u + (threadIdx.x & ((1u << u) - 1u))];
+            // an LDS BROADCAST read (the index is (lane >> LQ) & mask: not uniform, not a DPP row pattern); the ds_bpermute form
+            // measured 1-4 % slower (profiles/r02_twiddle_shuffle_vs_lds.txt)
 #pragma unroll
-                for (int jl = 0; jl < 8; jl++)
-                    if (jl < (1 << d)) w[jl] = (uint32_t)__shfl((int)mine, (int)(tlo | ((uint32_t)jl << A)), 64);
-            } else {
-#pragma unroll
-                for (int jl = 0; jl < 8; jl++)
-                    if (jl < (1 << d)) w[jl] = tw[(1u << u) - 1u + (tlo | ((uint32_t)jl << A))];
-            }
+            for (int jl = 0; jl < 8; jl++)
+                if (jl < (1 << d)) w[jl] = tw[(1u << u) - 1u + (tlo | ((uint32_t)jl << A))];
         }
 #pragma unroll
         for (int j0 = 0; j0 < 16; j0++) {
@@ -210,7 +149,6 @@ __device__ __forceinline__ void load_round1_twiddles(const uint32_t* __restrict_
 }
 template <class V>
 __device__ __forceinline__ void stage_block_round1(V (&v)[16], const uint32_t (&w1)[15]) {
-    if (NARROW_SKIP) { v[0] = add2(v[0], mul2(v[1], w1[0] & 1u)); return; }  // keep the twiddle loads alive
 #pragma unroll
     for (int d = 3; d >= 0; --d) {
 #pragma unroll
@@ -307,42 +245,14 @@ template <class V>
 __device__ __forceinline__ V ldv(const void* base, uint32_t off) {
     return *reinterpret_cast<const V*>(static_cast<const char*>(base) + off);
 }
-#ifndef NARROW_STORE_WT
-#define NARROW_STORE_WT 0  // 1: write-through stores (global_store ... sc1), 2: non-temporal; A/B: profiles/r03_store_policy_ab.txt
-#endif
 template <class V>
 __device__ __forceinline__ void stv(void* base, uint32_t off, V v) {
-    V* p = reinterpret_cast<V*>(static_cast<char*>(base) + off);
-#if NARROW_STORE_WT == 1
-    if constexpr (sizeof(V) == 8) {
-        unsigned long long x;
-        __builtin_memcpy(&x, &v, 8);
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        uint32_t x;
-        __builtin_memcpy(&x, &v, 4);
-        __hip_atomic_store(reinterpret_cast<uint32_t*>(p), x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#elif NARROW_STORE_WT == 2
-    if constexpr (sizeof(V) == 8) {
-        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        u32x2 x;
-        __builtin_memcpy(&x, &v, 8);
-        __builtin_nontemporal_store(x, reinterpret_cast<u32x2*>(p));
-    } else {
-        uint32_t x;
-        __builtin_memcpy(&x, &v, 4);
-        __builtin_nontemporal_store(x, reinterpret_cast<uint32_t*>(p));
-    }
-#else
-    *p = v;
-#endif
+    *reinterpret_cast<V*>(static_cast<char*>(base) + off) = v;
 }
 
 // v[j] *= c * phi^(idx(j)), idx(j) = REV ? rev4(j) : j
 template <bool REV, class V>
 __device__ __forceinline__ void scale_ladder(V (&v)[16], uint32_t c, uint32_t phi) {
-    if (NARROW_SKIP) { v[0] = add2(v[0], mul2(v[1], (c ^ phi) & 1u)); return; }
     uint32_t pw[16];
     power_ladder<16>(c, phi, pw);
 #pragma unroll
@@ -380,48 +290,17 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow_inv1_kernel(NarrowAr
     const uint32_t rowstride = a.W << a.n2;                               // words between r1 and r1 + 1
     const uint32_t ld_off = (VW * s + t * rowstride) * 4u;
     V v[16];
-    P3_STAMP_RT(a, 30);
-    if (NARROW_STAMPS && a.stamps && threadIdx.x == 0) a.stamps[((uint64_t)blockIdx.x) * 32u + 0] = __builtin_amdgcn_s_memtime();
 #pragma unroll
     for (uint32_t j = 0; j < 16; j++) v[j] = ldv<V>(a.src + ((uint64_t)j << (B - 4)) * rowstride, ld_off);
     uint32_t w1[15];
     load_round1_twiddles<B>(a.stage_tw, t, w1);
     for (uint32_t i = threadIdx.x; i + 1 < (1u << (B - 4)); i += NTH) twl[i] = a.stage_tw[i];
-    P3_STAMP(a, 1);
     // position (t << 4) | j holds k1 = rev_B(position) = (rev4(j) << (B-4)) | rev(t): twiddle w^-(lo * k1)
     const uint32_t c = two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)lo * rev_bits(t, B - 4));
     const uint32_t phi = two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)lo << (B - 4));
-    P3_STAMP(a, 2);
-#if NARROW_STAMPS
-    {
-        constexpr int A1 = B - 4, A2 = B > 8 ? B - 8 : 0;
-        stage_block_round1(v, w1);
-        P3_PIN16(v);
-        P3_STAMP(a, 8);
-        exchange<LQ, A1, A2, V>(tile, v, t, q);
-        P3_PIN16(v);
-        P3_STAMP(a, 9);
-        stage_block<A2, A1, A2>(v, twl, t);
-        P3_PIN16(v);
-        P3_STAMP(a, 10);
-        if constexpr (B > 8) {
-            exchange<LQ, A2, 0, V>(tile, v, t, q);
-            P3_PIN16(v);
-            P3_STAMP(a, 11);
-            stage_block<0, A2, 0>(v, twl, t);
-        }
-    }
-#else
     dif_rounds<B, LQ>(v, tile, w1, twl, t, q);
-#endif
-    P3_PIN16(v);
-    P3_STAMP(a, 3);
     scale_ladder<true>(v, c, phi);
-    P3_PIN16(v);
-    P3_STAMP(a, 4);
     to_natural<B, LQ>(tile, v, t, q);
-    P3_PIN16(v);
-    P3_STAMP(a, 5);
     // T[(lo * N1 + k1) * W + VW cp], k1 = pt_of<B-4>(t, j): consecutive lanes (cp, then k1) are contiguous for W <= NQ * VW
     if (a.blocked) {
         // W = 2: block (r2 >> 2, k1 >> 2) of 128 bytes holds the row pairs (r2 & 3, k1 & 3), 8 bytes each (cp = column
@@ -429,8 +308,6 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow_inv1_kernel(NarrowAr
         const uint32_t blk_off = ((((lo >> 2) << (B - 2)) + (t >> 2)) * 16u + (lo & 3u) * 4u + (t & 3u)) * 8u + cp * 4u;
 #pragma unroll
         for (uint32_t j = 0; j < 16; j++) stv<V>(a.dst + ((uint64_t)j << (B - 6)) * 32u, blk_off, v[j]);
-        P3_STAMP(a, 6);
-        P3_STAMP_RT(a, 31);
         return;
     }
     const uint32_t st_off = (((lo << B) + t) * a.W + VW * cp) * 4u;
@@ -439,19 +316,14 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow_inv1_kernel(NarrowAr
 }
 
 // K2: second inverse digit, then per coset: scale, first forward digit, twiddle, strided store.
-// SEQ (column pairs, 512-thread tiles = the 11- and 12-stage digits): the coset transforms run ONE COLUMN AT A TIME
-// on 32-bit registers and two 32-bit LDS tiles that alias the pair tile of the inverse phase; the pair's first
-// result waits in registers for the second and both are stored together.  Meant to fit 128 VGPRs and half the LDS
-// so that two workgroups share a CU; hipcc 7.2 spills instead, so it is compiled out by default (NARROW_MID_SEQ).
-template <int B, int LQ, int VW, bool SEQ>
-__global__ void __launch_bounds__(1 << (B - 4 + LQ), (SEQ ? NARROW_MID_SEQ_WAVES : ((B - 4 + LQ >= 9 && NARROW_MID_SHARE_CU) ? 4 : 1)))
+template <int B, int LQ, int VW>
+__global__ void __launch_bounds__(1 << (B - 4 + LQ), 1)
 narrow_mid_kernel(NarrowArgs a) {
     using namespace narrow;
     using V = typename Vec<VW>::T;
-    static_assert(!SEQ || VW == 2, "the column-sequential form is for column pairs");
     constexpr uint32_t NQ = 1u << LQ, NTH = 1u << (B - 4 + LQ);
     constexpr bool LEAN = NTH >= 512;  // at most 256 (1024 threads: 128) VGPRs per lane: rebuild the output ladder per coset
-    constexpr uint32_t NT = (SEQ || NTH >= 1024) ? 1 : NARROW_MID_TILES;
+    constexpr uint32_t NT = NTH >= 1024 ? 1 : NARROW_MID_TILES;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // two tiles (one barrier per hand-over): the 15 hand-overs of a blowup-4 middle pass are this kernel's stalls
     Tiles<V, (NT > 1)> tile{reinterpret_cast<V*>(smem), reinterpret_cast<V*>(smem) + (NT - 1) * (lds_rows(B) << LQ)};
@@ -486,43 +358,7 @@ narrow_mid_kernel(NarrowArgs a) {
     uint32_t sc_next = two_level(a.sc_lo[cos0], a.sc_hi[cos0], a.sc_T, kbase);
     // c[j] = coefficient k = k1 + N1 * k2, k2 = pt_of<B-4>(t, j) = (j << (B-4)) | t (what a coefficient matrix's rows already are)
     if (!a.from_coeffs) to_natural<B, LQ>(tile, c, t, q);
-    if constexpr (SEQ) {
-        __syncthreads();  // the 32-bit tiles below alias the pair tile: its last reads (to_natural) are done
-        Tiles<uint32_t, true> t32{smem, smem + (lds_rows(B) << LQ)};
-        for (uint32_t jc = cos0; jc < ncos; jc++) {
-            const uint32_t sc = sc_next;
-            if (jc + 1 < ncos) sc_next = two_level(a.sc_lo[jc + 1], a.sc_hi[jc + 1], a.sc_T, kbase);
-            // per column: round-1 twiddles and the scale ladder are rebuilt (15 loads + 18 products) rather than kept
-            // live across both columns — the 128-VGPR budget holds c (32), the first column's result (16) and v (16)
-            uint32_t r0[16], v[16];
-            {
-                uint32_t w1[15], pw[16];
-                load_round1_twiddles<B>(a.stage_tw_fwd, t, w1);
-                power_ladder<16>(sc, a.sc_phi[jc], pw);
-#pragma unroll
-                for (uint32_t j = 0; j < 16; j++) v[j] = bb::mul(c[j].x, pw[j]);
-                dif_rounds<B, LQ>(v, t32, w1, twl_f, t, q);
-            }
-#pragma unroll
-            for (uint32_t j = 0; j < 16; j++) r0[j] = v[j];
-            {
-                uint32_t w1[15], pw[16];
-                load_round1_twiddles<B>(a.stage_tw_fwd, t, w1);
-                power_ladder<16>(sc, a.sc_phi[jc], pw);
-#pragma unroll
-                for (uint32_t j = 0; j < 16; j++) v[j] = bb::mul(c[j].y, pw[j]);
-                dif_rounds<B, LQ>(v, t32, w1, twl_f, t, q);
-            }
-            uint32_t pw[16];
-            uint32_t* o = a.dst + ((uint64_t)rev_bits(jc, a.added) << a.n) * a.W;
-            power_ladder<16>(c0, phi0, pw);
-#pragma unroll
-            for (uint32_t j = 0; j < 16; j++) {
-                const uint32_t wj = pw[crev(j, 4)];
-                stv<V>(o + (uint64_t)j * rowstride, st_off, make_uint2(bb::mul(r0[j], wj), bb::mul(v[j], wj)));
-            }
-        }
-    } else {
+    {
         uint32_t pw2[16];
         if constexpr (!LEAN) power_ladder<16>(c0, phi0, pw2);
         for (uint32_t jc = cos0; jc < ncos; jc++) {
@@ -536,7 +372,7 @@ narrow_mid_kernel(NarrowArgs a) {
             scale_ladder<false>(v, sc, a.sc_phi[jc]);
             dif_rounds<B, LQ>(v, tile, w1, twl_f, t, q);
             uint32_t* o = a.dst + ((uint64_t)rev_bits(jc, a.added) << a.n) * a.W;  // position (t << 4) | j of the coset's block
-            if (blocked && !a.mid_handover) {
+            if (blocked) {
                 // blocked positions straight from the final layout: position (t << 4) | j -> block ((t << 2) | (j >> 2), k1 group)
                 const uint32_t fin_off = (((t << 2) << (a.n1 - 2)) + (k1 >> 2)) * 128u + (k1 & 3u) * 8u + (VW == 1 ? (s & 1u) * 4u : 0u);
                 uint32_t pwl[16];
@@ -544,18 +380,6 @@ narrow_mid_kernel(NarrowArgs a) {
 #pragma unroll
                 for (uint32_t j = 0; j < 16; j++)
                     stv<V>(o + ((uint64_t)(j >> 2) << (a.n1 - 2)) * 32u, fin_off + (j & 3u) * 32u, mul2(v[j], LEAN ? pwl[crev(j, 4)] : pw2[crev(j, 4)]));
-                continue;
-            }
-            if (blocked) {
-                // twiddle, then one more hand-over so that 16 consecutive lanes hold 16 consecutive rows: whole lines
-                if constexpr (LEAN) scale_ladder<true>(v, c0, phi0);
-                else {
-#pragma unroll
-                    for (uint32_t j = 0; j < 16; j++) v[j] = mul2(v[j], pw2[crev(j, 4)]);
-                }
-                to_rows<B, LQ>(tile, v, t, q);
-#pragma unroll
-                for (uint32_t j = 0; j < 16; j++) stv<V>(o + (uint64_t)j * blk_jstride, blk_off, v[j]);
                 continue;
             }
             if constexpr (LEAN) {

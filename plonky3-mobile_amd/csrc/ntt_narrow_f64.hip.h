@@ -9,8 +9,9 @@
 // Conversions: one v_cvt_f64_u32 per loaded word; 3 instructions per stored word when the value comes out of a product
 // (|r| <= P/2 + 1: convert, add P, min), 4 when it does not (floor-quotient reduction, below).  Between the register rounds the tile
 // is exchanged through LDS as doubles (one 8-byte plane per column of the lane's vector, the same padded layout and bank analysis
-// as the uint2 tiles of the integer kernels), or — XW kernels — as words (five more instructions per element and hand-over, the
-// integer kernels' LDS footprint); the last hand-over of K1 / K3 is always on words.
+// as the uint2 tiles of the integer kernels); the last hand-over of K1 / K3 is on words.  (A form with EVERY hand-over on words — five
+// more instructions per element and hand-over, the integer kernels' LDS footprint — lost by more at every size and was retired in
+// round 5: profiles/r04_lde_f64_vs_int.txt, 1461 against 1259 against 837 us at cfg3's shape.)
 //
 // What it bought (profiles/r03_pmc_lde_valu.json, r03_lde_f64_vs_int.txt): a third fewer VALU instructions
 // per wave and 2-8 % of the unit's time up to 2^20 rows — the unit is a chain of unoverlapped phases, and the hand-overs of doubles
@@ -61,10 +62,6 @@ __device__ __forceinline__ uint32_t word_any(double x, const Uni& u) {
 }
 
 template <int VW> struct DV { double c[VW]; };
-template <int VW> __device__ __forceinline__ void pin_value(DV<VW>& x) {
-#pragma unroll
-    for (int cc = 0; cc < VW; cc++) p3::pin_value(x.c[cc]);
-}
 
 template <int VW>
 __device__ __forceinline__ DV<VW> ld_words(const void* base, uint32_t off) {
@@ -153,47 +150,16 @@ __device__ __forceinline__ void exchange(TL& tiles, DV<VW> (&v)[16], uint32_t t,
 #pragma unroll
         for (int cc = 0; cc < VW; cc++) v[j].c[cc] = rp[cc * PL + lds_joff<LQ>(j << AT)];
 }
-// word of any integer |x| < 2^43 (defined below)
-__device__ __forceinline__ uint32_t word_any(double x, const Uni& u);
-template <int VW>
-__device__ __forceinline__ DV<VW> from_words(const typename Vec<VW>::T& x) {
-    DV<VW> r;
-    if constexpr (VW == 2) { r.c[0] = (double)x.x; r.c[1] = (double)x.y; }
-    else r.c[0] = (double)x;
-    return r;
-}
-template <int VW>
-__device__ __forceinline__ typename Vec<VW>::T words_of(const DV<VW>& v, const Uni& u) {
-    if constexpr (VW == 2) return make_uint2(word_any(v.c[0], u), word_any(v.c[1], u));
-    else return word_any(v.c[0], u);
-}
-// The same hand-over on WORDS (XW kernels): every value is reduced to its word on the way in (4 instructions) and converted back on
-// the way out (1): five instructions per element instead of twice the LDS bytes — the tiles, and with them the workgroups per CU, are
-// those of the integer kernels.
-template <int LQ, int AF, int AT, int VW, class TL>
-__device__ __forceinline__ void exchange_xw(TL& tiles, DV<VW> (&v)[16], uint32_t t, uint32_t q, const Uni& un) {
-    using WV = typename Vec<VW>::T;
-    WV* tile = reinterpret_cast<WV*>(tiles.next());
-    WV* wp = tile + lds_base<LQ, AF>(t, q);
-#pragma unroll
-    for (uint32_t j = 0; j < 16; j++) wp[lds_joff<LQ>(j << AF)] = words_of<VW>(v[j], un);
-    __syncthreads();
-    const WV* rp = tile + lds_base<LQ, AT>(t, q);
-#pragma unroll
-    for (uint32_t j = 0; j < 16; j++) v[j] = from_words<VW>(rp[lds_joff<LQ>(j << AT)]);
-}
-template <int B, int LQ, bool XW, int VW, class TL>
+template <int B, int LQ, int VW, class TL>
 __device__ __forceinline__ void dif_rounds(DV<VW> (&v)[16], TL& tile, const double (&w1)[15], const double2* twl, uint32_t t, uint32_t q,
                                            const Magic& k, const Uni& un) {
     constexpr int A1 = B - 4, A2 = B > 8 ? B - 8 : 0;
     constexpr uint32_t PL = lds_rows(B) << LQ;
     stage_block_round1(v, w1, k, un);
-    if constexpr (XW) exchange_xw<LQ, A1, A2>(tile, v, t, q, un);
-    else exchange<LQ, A1, A2, PL>(tile, v, t, q);
+    exchange<LQ, A1, A2, PL>(tile, v, t, q);
     stage_block<A2, A1, A2>(v, twl, t, k, un.npm1);
     if constexpr (B > 8) {
-        if constexpr (XW) exchange_xw<LQ, A2, 0>(tile, v, t, q, un);
-        else exchange<LQ, A2, 0, PL>(tile, v, t, q);
+        exchange<LQ, A2, 0, PL>(tile, v, t, q);
         stage_block<0, A2, 0>(v, twl, t, k, un.npm1);
     }
 }
@@ -214,20 +180,6 @@ __device__ __forceinline__ void to_natural(TL& tiles, DV<VW> (&v)[16], uint32_t 
     for (uint32_t j = 0; j < 16; j++)
 #pragma unroll
         for (int cc = 0; cc < VW; cc++) v[j].c[cc] = rp[cc * PL + lds_joff<LQ>(j << (B - 4))];
-}
-
-template <int B, int LQ, int VW, class TL>
-__device__ __forceinline__ void to_natural_xw(TL& tiles, DV<VW> (&v)[16], uint32_t t, uint32_t q, const Uni& un) {
-    using WV = typename Vec<VW>::T;
-    WV* tile = reinterpret_cast<WV*>(tiles.next());
-    const uint32_t rt = rev_bits(t, B - 4);
-    WV* wp = tile + (((rt + (rt >> 4)) << LQ) + q);
-#pragma unroll
-    for (uint32_t j = 0; j < 16; j++) wp[lds_joff<LQ>(crev(j, 4) << (B - 4))] = words_of<VW>(v[j], un);
-    __syncthreads();
-    const WV* rp = tile + lds_base<LQ, B - 4>(t, q);
-#pragma unroll
-    for (uint32_t j = 0; j < 16; j++) v[j] = from_words<VW>(rp[lds_joff<LQ>(j << (B - 4))]);
 }
 
 // The LAST hand-over of K1 (to natural frequency order) and K3 (to row order) on WORDS: the values are reduced for the store
@@ -286,21 +238,21 @@ __device__ __forceinline__ void scale_by(DV<VW> (&v)[16], const double (&pw)[16]
     }
 }
 
-template <int B, int LQ, int VW, int NT, bool XW>
+template <int B, int LQ, int VW, int NT>
 constexpr size_t lds_bytes(int tables) {
-    return ((size_t)(XW ? 4 : 8) * VW * NT * lds_rows(B) << LQ) + (size_t)tables * ((size_t)16 << (B - 4));
+    return ((size_t)8 * VW * NT * lds_rows(B) << LQ) + (size_t)tables * ((size_t)16 << (B - 4));
 }
 
 }  // namespace narrow64
 
 // K1: first inverse digit (the high n1 bits of the row index), inter-digit twiddle, transposed store.
-template <int B, int LQ, int VW, int NT, bool XW>
+template <int B, int LQ, int VW, int NT>
 __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow64_inv1_kernel(NarrowArgs a) {
     using namespace narrow64;
     constexpr uint32_t NQ = 1u << LQ, NTH = 1u << (B - 4 + LQ), PL = lds_rows(B) << LQ;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     double* t0 = reinterpret_cast<double*>(smem);
-    constexpr uint32_t TD = XW ? VW * PL / 2 : VW * PL;  // doubles per tile (a tile of words is half as large)
+    constexpr uint32_t TD = VW * PL;  // doubles per tile
     Tiles<double, (NT > 1)> tile{t0, t0 + (NT - 1) * TD};
     double2* twl = reinterpret_cast<double2*>(t0 + NT * TD);
     const Magic mk = pin_magic();
@@ -311,62 +263,28 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow64_inv1_kernel(Narrow
     const uint32_t rowstride = a.W << a.n2;
     const uint32_t ld_off = (VW * s + t * rowstride) * 4u;
     DV<VW> v[16];
-    P3_STAMP_RT(a, 30);
-    if (NARROW_STAMPS && a.stamps && threadIdx.x == 0) a.stamps[((uint64_t)blockIdx.x) * 32u + 0] = __builtin_amdgcn_s_memtime();
 #pragma unroll
     for (uint32_t j = 0; j < 16; j++) v[j] = ld_words<VW>(a.src + ((uint64_t)j << (B - 4)) * rowstride, ld_off);
     double w1[15];
     load_round1_twiddles<B>(a.stage_twd, t, w1);
     for (uint32_t i = threadIdx.x; i + 1 < (1u << (B - 4)); i += NTH) twl[i] = a.stage_twd[i];
-    P3_PIN16(v);
-    P3_STAMP(a, 1);
     const double c = canon(two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)lo * rev_bits(t, B - 4)));
     const double phi = canon(two_level(a.tw_lo, a.tw_hi, a.tw_T, (uint64_t)lo << (B - 4)));
-    P3_STAMP(a, 2);
-#if NARROW_STAMPS
-    {
-        constexpr int A1 = B - 4, A2 = B > 8 ? B - 8 : 0;
-        stage_block_round1(v, w1, mk, un);
-        P3_PIN16(v);
-        P3_STAMP(a, 8);
-        if constexpr (XW) exchange_xw<LQ, A1, A2>(tile, v, t, q, un); else exchange<LQ, A1, A2, PL>(tile, v, t, q);
-        P3_PIN16(v);
-        P3_STAMP(a, 9);
-        stage_block<A2, A1, A2>(v, twl, t, mk, un.npm1);
-        P3_PIN16(v);
-        P3_STAMP(a, 10);
-        if constexpr (B > 8) {
-            if constexpr (XW) exchange_xw<LQ, A2, 0>(tile, v, t, q, un); else exchange<LQ, A2, 0, PL>(tile, v, t, q);
-            P3_PIN16(v);
-            P3_STAMP(a, 11);
-            stage_block<0, A2, 0>(v, twl, t, mk, un.npm1);
-        }
-    }
-#else
-    dif_rounds<B, LQ, XW>(v, tile, w1, twl, t, q, mk, un);
-#endif
-    P3_PIN16(v);
-    P3_STAMP(a, 3);
+    dif_rounds<B, LQ>(v, tile, w1, twl, t, q, mk, un);
     {
         double pw[16];
         power_ladder16(c, phi, pw, mk, un);
         scale_by<true>(v, pw, mk, un);
     }
-    P3_PIN16(v);
-    P3_STAMP(a, 4);
     using WV = typename Vec<VW>::T;
     WV w[16];
 #pragma unroll
     for (uint32_t j = 0; j < 16; j++) w[j] = to_words<VW, true>(v[j], un);
     exchange_words<B, LQ, VW, true>(tile, w, t, q);
-    P3_PIN16(w);
-    P3_STAMP(a, 5);
     if (a.blocked) {
         const uint32_t blk_off = ((((lo >> 2) << (B - 2)) + (t >> 2)) * 16u + (lo & 3u) * 4u + (t & 3u)) * 8u + cp * 4u;
 #pragma unroll
         for (uint32_t j = 0; j < 16; j++) stv<WV>(a.dst + ((uint64_t)j << (B - 6)) * 32u, blk_off, w[j]);
-        P3_STAMP(a, 6);
-        P3_STAMP_RT(a, 31);
         return;
     }
     const uint32_t st_off = (((lo << B) + t) * a.W + VW * cp) * 4u;
@@ -375,13 +293,13 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow64_inv1_kernel(Narrow
 }
 
 // K2: second inverse digit; per coset: scale by (shift g^j)^k / N, first forward digit, twiddle, strided store.
-template <int B, int LQ, int VW, int NT, bool LEAN, bool XW>
+template <int B, int LQ, int VW, int NT, bool LEAN>
 __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow64_mid_kernel(NarrowArgs a) {
     using namespace narrow64;
     constexpr uint32_t NQ = 1u << LQ, NTH = 1u << (B - 4 + LQ), PL = lds_rows(B) << LQ;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     double* t0 = reinterpret_cast<double*>(smem);
-    constexpr uint32_t TD = XW ? VW * PL / 2 : VW * PL;
+    constexpr uint32_t TD = VW * PL;
     Tiles<double, (NT > 1)> tile{t0, t0 + (NT - 1) * TD};
     double2* twl_i = reinterpret_cast<double2*>(t0 + NT * TD);
     double2* twl_f = twl_i + (1u << (B - 4));
@@ -405,7 +323,7 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow64_mid_kernel(NarrowA
         load_round1_twiddles<B>(a.stage_twd, t, w1);
         for (uint32_t i = threadIdx.x; i + 1 < (1u << (B - 4)); i += NTH) twl_i[i] = a.stage_twd[i];
         for (uint32_t i = threadIdx.x; i + 1 < (1u << (B - 4)); i += NTH) twl_f[i] = a.stage_twd_fwd[i];
-        if (!a.from_coeffs) dif_rounds<B, LQ, XW>(c, tile, w1, twl_i, t, q, mk, un);
+        if (!a.from_coeffs) dif_rounds<B, LQ>(c, tile, w1, twl_i, t, q, mk, un);
     }
     const double c0 = canon(two_level(a.twf_lo, a.twf_hi, a.twf_T, (uint64_t)k1 * rev_bits(t, B - 4)));
     const double phi0 = canon(two_level(a.twf_lo, a.twf_hi, a.twf_T, (uint64_t)k1 << (B - 4)));
@@ -413,8 +331,7 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow64_mid_kernel(NarrowA
     const uint32_t cos0 = blockIdx.y * a.cos_per_block, ncos = cos0 + a.cos_per_block;
     uint32_t sc_next = two_level(a.sc_lo[cos0], a.sc_hi[cos0], a.sc_T, kbase);
     if (!a.from_coeffs) {  // c[j] = coefficient k = k1 + N1 * k2, k2 = (j << (B-4)) | t
-        if constexpr (XW) to_natural_xw<B, LQ>(tile, c, t, q, un);
-        else to_natural<B, LQ>(tile, c, t, q);
+        to_natural<B, LQ>(tile, c, t, q);
     }
     double pw2[16];
     if constexpr (!LEAN) power_ladder16(c0, phi0, pw2, mk, un);
@@ -434,7 +351,7 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow64_mid_kernel(NarrowA
                 for (int cc = 0; cc < VW; cc++) v[j].c[cc] = mulm(w, wP, c[j].c[cc], mk, un.npm1);
             }
         }
-        dif_rounds<B, LQ, XW>(v, tile, w1, twl_f, t, q, mk, un);
+        dif_rounds<B, LQ>(v, tile, w1, twl_f, t, q, mk, un);
         if constexpr (LEAN) power_ladder16(c0, phi0, pw2, mk, un);
         scale_by<true>(v, pw2, mk, un);
         uint32_t* o = a.dst + ((uint64_t)rev_bits(jc, a.added) << a.n) * a.W;  // position (t << 4) | j of the coset's block
@@ -452,13 +369,13 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow64_mid_kernel(NarrowA
 }
 
 // K3: last forward digit on contiguous blocks of 2^B rows, in place.
-template <int B, int LQ, int VW, int NT, bool XW>
+template <int B, int LQ, int VW, int NT>
 __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow64_fwd2_kernel(NarrowArgs a) {
     using namespace narrow64;
     constexpr uint32_t NQ = 1u << LQ, NTH = 1u << (B - 4 + LQ), PL = lds_rows(B) << LQ;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     double* t0 = reinterpret_cast<double*>(smem);
-    constexpr uint32_t TD = XW ? VW * PL / 2 : VW * PL;  // doubles per tile (a tile of words is half as large)
+    constexpr uint32_t TD = VW * PL;  // doubles per tile
     Tiles<double, (NT > 1)> tile{t0, t0 + (NT - 1) * TD};
     double2* twl = reinterpret_cast<double2*>(t0 + NT * TD);
     const Magic mk = pin_magic();
@@ -483,7 +400,7 @@ __global__ void __launch_bounds__(1 << (B - 4 + LQ)) narrow64_fwd2_kernel(Narrow
     double w1[15];
     load_round1_twiddles<B>(a.stage_twd, t, w1);
     for (uint32_t i = threadIdx.x; i + 1 < (1u << (B - 4)); i += NTH) twl[i] = a.stage_twd[i];
-    dif_rounds<B, LQ, XW>(v, tile, w1, twl, t, q, mk, un);
+    dif_rounds<B, LQ>(v, tile, w1, twl, t, q, mk, un);
     using WV = typename Vec<VW>::T;
     WV w[16];
 #pragma unroll

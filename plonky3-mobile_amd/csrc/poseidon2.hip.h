@@ -120,32 +120,4 @@ BB_HD void permute(uint32_t (&s)[16]) {
 }
 
 
-// Two independent states per lane, advanced round by round together: twice the instruction-level parallelism
-// for the same code size (used where a lane has two permutations to do anyway).
-BB_HD void permute2(uint32_t (&s)[16], uint32_t (&t)[16]) {
-    external_linear(s);
-    external_linear(t);
-    P2_ROLLED
-    for (int r = 0; r < 4; r++) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) { s[i] = bb::sbox7_add(s[i], P2_RC.ext[r][i]); t[i] = bb::sbox7_add(t[i], P2_RC.ext[r][i]); }
-        external_linear(s);
-        external_linear(t);
-    }
-    P2_ROLLED
-    for (int r = 0; r < 13; r++) {
-        s[0] = bb::sbox7_add(s[0], P2_RC.in[r]);
-        t[0] = bb::sbox7_add(t[0], P2_RC.in[r]);
-        internal_linear(s);
-        internal_linear(t);
-    }
-    P2_ROLLED
-    for (int r = 4; r < 8; r++) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) { s[i] = bb::sbox7_add(s[i], P2_RC.ext[r][i]); t[i] = bb::sbox7_add(t[i], P2_RC.ext[r][i]); }
-        external_linear(s);
-        external_linear(t);
-    }
-}
-
 }  // namespace p2

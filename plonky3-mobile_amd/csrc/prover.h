@@ -13,6 +13,12 @@ struct FriParams {
     uint32_t log_blowup, log_final_poly_len, num_queries, proof_of_work_bits;
 };
 
+// Largest LDE domain (log2 of its points) a prover object admits: BASELINE configs[2] (2^24 rows at blowup 4) — the largest
+// size any test or bench has run; the field's two-adicity (27) would admit twice that, which nothing has ever exercised.
+constexpr uint32_t MAX_LOG_DOMAIN = 26;
+// the hiding prover's (log_n + 1 + log_blowup): 2^22 trace rows at blowup 2, exercised by tests/test_gpu_hiding.py
+constexpr uint32_t MAX_LOG_DOMAIN_HIDING = 24;
+
 struct StageTimes {  // host wall clock per stage, accumulated over `proofs`
     double trace_commit_ms = 0, quotient_commit_ms = 0, open_ms = 0, fri_commit_ms = 0, grind_ms = 0, query_ms = 0;
     uint64_t proofs = 0;
@@ -23,7 +29,8 @@ class FibProver {
     FibProver();
     ~FibProver();
     FibProver(const FibProver&) = delete;
-    int init(uint32_t log_n, const FriParams& fp, hipStream_t stream, bool own_stream, int hash = 0);  // mmcs.h HashKind
+    // hash: mmcs.h HashKind; profile: common.h Profile (a lone prover: latency; provers sharing the chip: throughput)
+    int init(uint32_t log_n, const FriParams& fp, hipStream_t stream, bool own_stream, int hash = 0, int profile = PROFILE_LATENCY);
     // proves the FibonacciAir instance with first row (a, b); public values [a, b, last right value]
     int prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof);
     // the same in two halves: enqueue returns once the proof's launches are queued (at most two proofs in flight, the second
@@ -49,7 +56,7 @@ class FibHidingProver {
     FibHidingProver();
     ~FibHidingProver();
     FibHidingProver(const FibHidingProver&) = delete;
-    int init(uint32_t log_n, const FriParams& fp, hipStream_t stream, bool own_stream, int hash, uint64_t seed);
+    int init(uint32_t log_n, const FriParams& fp, hipStream_t stream, bool own_stream, int hash, uint64_t seed, int profile = PROFILE_LATENCY);
     int prove(uint64_t a, uint64_t b, std::vector<uint8_t>* proof);
 
   private:

@@ -647,6 +647,7 @@ constexpr int N_STAGE_EVENTS = 7;
 
 struct FibProver::Impl {
     int hash = HASH_POSEIDON2;
+    int profile = PROFILE_LATENCY;
     int device = -1;  // the arena's device: prove() refuses to run with another one current
     uint32_t log_n = 0, log_big = 0;
     FriParams fp{};
@@ -694,15 +695,17 @@ struct FibProver::Impl {
 FibProver::FibProver() : im(new Impl()) {}
 FibProver::~FibProver() { delete im; }
 
-int FibProver::init(uint32_t log_n, const FriParams& fp, hipStream_t stream, bool own_stream, int hash) {
+int FibProver::init(uint32_t log_n, const FriParams& fp, hipStream_t stream, bool own_stream, int hash, int profile) {
     Impl& s = *im;
+    if (profile != PROFILE_THROUGHPUT && profile != PROFILE_LATENCY) return fail(ERR_BAD_ARG, "fib prover: unknown profile");
+    s.profile = profile;
     s.stream = stream; s.own_stream = own_stream;  // first: an owned stream is destroyed with the prover even when init fails
     if (hash != HASH_POSEIDON2 && hash != HASH_KECCAK) return fail(ERR_BAD_ARG, "fib prover: unknown hash configuration");
     im->hash = hash;
     P3_HIP(hipGetDevice(&s.device));
     if (log_n < 1) return fail(ERR_BAD_ARG, "fib prover: log_n must be >= 1");
-    if (log_n + fp.log_blowup > bb::TWO_ADICITY || log_n + fp.log_blowup > 31)
-        return fail(ERR_BAD_ARG, "fib prover: LDE height exceeds two-adicity");
+    if (log_n + fp.log_blowup > MAX_LOG_DOMAIN)
+        return fail(ERR_BAD_ARG, "fib prover: LDE domain above 2^" + std::to_string(MAX_LOG_DOMAIN) + " points (log_n + log_blowup)");
     if (fp.log_blowup < 1) return fail(ERR_BAD_ARG, "fib prover: log_blowup must be >= 1");
     // p3_fri::prover::prove: `if log_final_poly_len > 0 { assert!(log_min_height > log_final_poly_len + log_blowup) }`
     if (fp.log_final_poly_len > log_n || (fp.log_final_poly_len > 0 && fp.log_final_poly_len >= log_n))
@@ -855,7 +858,7 @@ int FibProver::run(uint64_t a, uint64_t b, int slot, int phase, std::vector<uint
         const uint32_t* mp[1] = {mat};
         size_t hh[1] = {h}, ww[1] = {w};
         Tree* tp = nullptr;
-        int r = mmcs_commit(st, mp, hh, ww, 1, &tp, layers, s.pstage + root_slot, s.hash);
+        int r = mmcs_commit(st, mp, hh, ww, 1, &tp, layers, s.pstage + root_slot, s.hash, nullptr, s.profile);
         if (r) return r;
         std::unique_ptr<Tree> t(tp);  // the layers live in the arena; the descriptor is not needed again
         if (!t->root_copied)
@@ -952,13 +955,12 @@ int FibProver::run(uint64_t a, uint64_t b, int slot, int phase, std::vector<uint
         }
 
         // ---- FRI commit phase ----
-        // P3HIP_FRI_TAIL=1: rounds whose layer has at most 2^7 rows in ONE launch (fri_tail_kernel; Poseidon2 hashes).  Built because the
-        // review asked for it, measured, and left OFF: a 2^20 proof 3.51 against 3.52 ms (the rounds are a chain of permutation
+        // LATENCY profile: rounds whose layer has at most 2^7 rows in ONE launch (fri_tail_kernel; Poseidon2 hashes).  Worth little:
+        // a 2^20 proof 3.51 against 3.52 ms (the rounds are a chain of permutation
         // latencies either way, the ~30 launches they save cost little on a stream that is waiting anyway), a 2^10 proof 0.705 ->
         // 0.678 ms, four provers 584 -> 580 proofs/s (profiles/r04_latency_ab.txt)
-        static const bool tail_on = [] { const char* e = getenv("P3HIP_FRI_TAIL"); return e && atoi(e) != 0; }();
         uint32_t r_tail = s.n_rounds;
-        if (tail_on && s.hash == HASH_POSEIDON2)
+        if (s.profile == PROFILE_LATENCY && s.hash == HASH_POSEIDON2)
             while (r_tail > 0 && (big >> (r_tail - 1)) <= (1u << FRI_TAIL_MAX_LOG)) r_tail--;
         for (uint32_t r = 0; r < r_tail; r++) {
             uint32_t len = big >> r, half = len >> 1;

@@ -15,9 +15,8 @@
 //     counts into output offsets; pass 2 (one wave per chunk, 16-byte loads) compacts the accepted candidates to their places
 //     with a wave scan — neighbours write neighbours; the lane that holds the n-th value replays its chunk from the saved state
 //     up to that draw and writes the generator state back to the stream, so the next fill continues exactly where a host loop
-//     would.  (First form, P3HIP_RNG_TWO_PASS=1: pass 1 only counted and pass 2 generated every draw again, each lane writing
-//     4-byte words 960 bytes from its neighbour's: 31 instead of 50 instructions per draw and coalesced stores bought the
-//     hiding bench 3.4 %.)
+//     would.  (The first form — pass 1 only counted and pass 2 generated every draw again, each lane writing 4-byte words 960
+//     bytes from its neighbour's — cost 50 instead of 31 instructions per draw and 3.4 % of the hiding bench; retired in round 5.)
 // Nothing synchronises with the host.  A fill that runs out of raw draws (probability far below 2^-100 with the margin
 // used) raises the error word instead of producing a short stream.
 #include "bb31.hip.h"
@@ -160,31 +159,6 @@ __device__ __forceinline__ void from_interleaved(uint64_t (&s)[4]) {
 #pragma unroll
     for (int w = 0; w < 4; w++) s[w] = out[w];
 }
-// One wave per 64 consecutive chunks: the wave jumps to its first chunk with the matrices of the set bits of that
-// chunk index (bits >= 6), then walks J_0 = T^CHUNK sixty-three times, lane i keeping the i-th state; every lane then
-// counts the accepted draws of its chunk.
-__global__ void __launch_bounds__(64) rng_pass1_kernel(const DevRng* st, const uint64_t* __restrict__ jump, uint32_t n_chunks,
-                                                       uint32_t n_bits, uint64_t* states, uint32_t* counts) {
-    const uint32_t lane = threadIdx.x, first = blockIdx.x * 64u, t = first + lane;
-    uint64_t cur[4] = {st->s[0], st->s[1], st->s[2], st->s[3]};
-    to_interleaved(cur);
-    const LaneRows j0 = load_rows(jump);
-    for (uint32_t k = 6; k < n_bits; k++)
-        if ((first >> k) & 1u) wave_matvec(load_rows(jump + (size_t)k * 256 * 4), cur);  // uniform branch
-    uint64_t s[4] = {cur[0], cur[1], cur[2], cur[3]};
-    const uint32_t last = n_chunks - first < 64u ? n_chunks - first : 64u;  // chunks of this wave
-    for (uint32_t i = 1; i < last; i++) {
-        wave_matvec(j0, cur);
-        if (lane == i) { s[0] = cur[0]; s[1] = cur[1]; s[2] = cur[2]; s[3] = cur[3]; }
-    }
-    if (t >= n_chunks) return;
-    from_interleaved(s);
-#pragma unroll
-    for (int w = 0; w < 4; w++) states[(size_t)t * 4 + w] = s[w];
-    uint32_t cnt = 0;
-    for (uint32_t i = 0; i < RNG_CHUNK; i++) cnt += ((uint32_t)(xoshiro_next(s) >> 32) >> 1) < bb::P ? 1u : 0u;
-    counts[t] = cnt;
-}
 // exclusive scan of counts[0..n) in two levels: every workgroup scans its 1024 counts in place and leaves their total in
 // bsum[block]; one workgroup then scans the block totals; pass 2 adds bsum[chunk / 1024] to the in-block offset.
 // (One workgroup walking the whole array took 183 us for the 2^17.8 chunks of the prover's largest fill.)
@@ -231,29 +205,9 @@ __global__ void __launch_bounds__(1024) rng_scan_kernel(uint32_t* counts, uint32
     uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
     for (uint32_t i = lo; i < hi; i++) { uint32_t c = counts[i]; counts[i] = run; run += c; }
 }
-__global__ void __launch_bounds__(256) rng_pass2_kernel(DevRng* st, const uint64_t* states, const uint32_t* offsets, const uint32_t* bsum,
-                                                        uint32_t n_chunks, uint32_t* out, uint64_t n, uint32_t* err) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_chunks) return;
-    uint64_t s[4] = {states[(size_t)t * 4], states[(size_t)t * 4 + 1], states[(size_t)t * 4 + 2], states[(size_t)t * 4 + 3]};
-    uint64_t pos = (uint64_t)offsets[t] + bsum[t / SCAN_TILE];
-    if (pos >= n) return;  // the stream was complete before this chunk
-    for (uint32_t i = 0; i < RNG_CHUNK; i++) {
-        const uint32_t v = (uint32_t)(xoshiro_next(s) >> 32) >> 1;
-        if (v < bb::P) {
-            out[pos++] = v;
-            if (pos == n) {  // the n-th element: the stream continues right after this draw
-#pragma unroll
-                for (int w = 0; w < 4; w++) st->s[w] = s[w];
-                return;
-            }
-        }
-    }
-    if (t + 1 == n_chunks) atomicOr(err, 1u);  // ran out of raw draws (never, with the margin of rng_fill_field)
-}
-
-// ---- one generation per draw (the default): pass 1 keeps the RAW 31-bit candidates, pass 2 only compacts them ----
-// Pass 1 as above (jump, walk, count), but every candidate is kept: the wave's 64 lanes (= 64 chunks) produce one candidate each
+// ---- one generation per draw: pass 1 keeps the RAW 31-bit candidates, pass 2 only compacts them ----
+// Pass 1: one wave per 64 x SUB consecutive chunks — the wave jumps to its first chunk with the matrices of the set bits of that chunk
+// index, then walks J_0 = T^CHUNK to the next ones, lane i keeping the i-th state — and every candidate is kept: the wave's 64 lanes (= 64 chunks) produce one candidate each
 // per step; 32 steps fill a 64 x 32 tile in LDS, which goes out transposed — lanes 0..31 write 128 contiguous bytes of one
 // chunk, lanes 32..63 of the next — so raw[chunk][0..256) is written in whole 128-byte pieces instead of 4-byte words 1 KB apart.
 // SUB consecutive chunks per lane (template): the walk that hands every lane its first state costs ~80 wave-instructions per lane
@@ -465,11 +419,10 @@ int rng_fill_field(Context& cx, hipStream_t stream, DevRng* st, uint32_t* out, u
     }
     // raw draws: n / (P / 2^31) = n * 1.0667 expected; 12.5 % + 64 chunks of margin is > 50 standard deviations
     {   // small fills: one launch (rng_small_fill_kernel).  Margin: n / 8 + 1024 raw draws beyond n is > 50 standard deviations of the
-        // rejections for every n (expected n / 15, deviation 0.27 sqrt(n)); P3HIP_RNG_SMALL=0 keeps the general path
-        static const bool small_on = [] { const char* e = getenv("P3HIP_RNG_SMALL"); return !e || atoi(e) != 0; }();
+        // rejections for every n (expected n / 15, deviation 0.27 sqrt(n))
         const uint64_t raw_small = n + n / 8 + 1024;
         const uint64_t chunks_small = (raw_small + RNG_CHUNK - 1) / RNG_CHUNK;
-        if (small_on && chunks_small <= RNG_SMALL_CHUNKS) {
+        if (chunks_small <= RNG_SMALL_CHUNKS) {
             hipLaunchKernelGGL(rng_small_fill_kernel, dim3(1), dim3(64), 0, stream, st, cx.rng_jump, (uint32_t)chunks_small, out, (uint32_t)n, err);
             P3_HIP(hipGetLastError());
             return OK;
@@ -483,37 +436,22 @@ int rng_fill_field(Context& cx, hipStream_t stream, DevRng* st, uint32_t* out, u
     while ((1u << n_bits) < chunks) n_bits++;
     uint64_t* states = reinterpret_cast<uint64_t*>(workspace);
     uint32_t* counts = workspace + (size_t)chunks * 8;
-    const uint32_t blocks = (chunks + 255) / 256;
-    // P3HIP_RNG_TWO_PASS=1: the first form (every draw generated twice: counted, then written by its own lane)
-    static const bool two_pass = [] { const char* e = getenv("P3HIP_RNG_TWO_PASS"); return e && atoi(e) != 0; }();
     const uint32_t tiles = (chunks + SCAN_TILE - 1) / SCAN_TILE;
     uint32_t* bsum = counts + chunks;
-    if (!two_pass) {
-        // raw candidates behind the block totals, 16-byte aligned
-        uint32_t* raw = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(bsum + tiles + 1) + 15u) & ~(uintptr_t)15u);
-        // chunks per lane: the most that still leaves the chip >= 1024 waves (P3HIP_RNG_SUB_LOG forces 0..2)
-        static const int sub_env = [] { const char* e = getenv("P3HIP_RNG_SUB_LOG"); return e ? atoi(e) : -1; }();
-        const uint32_t sub_log = sub_env >= 0 ? (uint32_t)std::min(sub_env, 2) : (chunks >= (1024u * 64u * 4u) ? 2u : chunks >= (1024u * 64u * 2u) ? 1u : 0u);
-        const dim3 grid((chunks + (64u << sub_log) - 1) / (64u << sub_log));
-        if (sub_log == 2) hipLaunchKernelGGL(rng_gen_kernel<2>, grid, dim3(64), 0, stream, st, cx.rng_jump, chunks, n_bits, states, counts, raw);
-        else if (sub_log == 1) hipLaunchKernelGGL(rng_gen_kernel<1>, grid, dim3(64), 0, stream, st, cx.rng_jump, chunks, n_bits, states, counts, raw);
-        else hipLaunchKernelGGL(rng_gen_kernel<0>, grid, dim3(64), 0, stream, st, cx.rng_jump, chunks, n_bits, states, counts, raw);
-        P3_HIP(hipGetLastError());
-        hipLaunchKernelGGL(rng_scan_tiles_kernel, dim3(tiles), dim3(256), 0, stream, counts, chunks, bsum);
-        P3_HIP(hipGetLastError());
-        hipLaunchKernelGGL(rng_scan_kernel, dim3(1), dim3(1024), 0, stream, bsum, tiles);
-        P3_HIP(hipGetLastError());
-        hipLaunchKernelGGL(rng_compact_kernel, dim3((chunks + 3) / 4), dim3(256), 0, stream, st, states, counts, bsum, chunks, raw, out, n, err);
-        P3_HIP(hipGetLastError());
-        return OK;
-    }
-    hipLaunchKernelGGL(rng_pass1_kernel, dim3((chunks + 63) / 64), dim3(64), 0, stream, st, cx.rng_jump, chunks, n_bits, states, counts);
+    // raw candidates behind the block totals, 16-byte aligned
+    uint32_t* rawc = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(bsum + tiles + 1) + 15u) & ~(uintptr_t)15u);
+    // chunks per lane: the most that still leaves the chip >= 1024 waves
+    const uint32_t sub_log = chunks >= (1024u * 64u * 4u) ? 2u : chunks >= (1024u * 64u * 2u) ? 1u : 0u;
+    const dim3 grid((chunks + (64u << sub_log) - 1) / (64u << sub_log));
+    if (sub_log == 2) hipLaunchKernelGGL(rng_gen_kernel<2>, grid, dim3(64), 0, stream, st, cx.rng_jump, chunks, n_bits, states, counts, rawc);
+    else if (sub_log == 1) hipLaunchKernelGGL(rng_gen_kernel<1>, grid, dim3(64), 0, stream, st, cx.rng_jump, chunks, n_bits, states, counts, rawc);
+    else hipLaunchKernelGGL(rng_gen_kernel<0>, grid, dim3(64), 0, stream, st, cx.rng_jump, chunks, n_bits, states, counts, rawc);
     P3_HIP(hipGetLastError());
     hipLaunchKernelGGL(rng_scan_tiles_kernel, dim3(tiles), dim3(256), 0, stream, counts, chunks, bsum);
     P3_HIP(hipGetLastError());
     hipLaunchKernelGGL(rng_scan_kernel, dim3(1), dim3(1024), 0, stream, bsum, tiles);
     P3_HIP(hipGetLastError());
-    hipLaunchKernelGGL(rng_pass2_kernel, dim3(blocks), dim3(256), 0, stream, st, states, counts, bsum, chunks, out, n, err);
+    hipLaunchKernelGGL(rng_compact_kernel, dim3((chunks + 3) / 4), dim3(256), 0, stream, st, states, counts, bsum, chunks, rawc, out, n, err);
     P3_HIP(hipGetLastError());
     return OK;
 }

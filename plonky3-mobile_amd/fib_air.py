@@ -38,26 +38,47 @@ def _hash_kind(hash):
     return kinds[hash]
 
 
+PROFILE_THROUGHPUT, PROFILE_LATENCY = 1, 2  # include/p3hip.h P3HIP_PROFILE_*
+
+
+def profile_kind(profile):
+    try:
+        return {"throughput": PROFILE_THROUGHPUT, "latency": PROFILE_LATENCY, PROFILE_THROUGHPUT: PROFILE_THROUGHPUT,
+                PROFILE_LATENCY: PROFILE_LATENCY}[profile]
+    except KeyError:
+        raise ValueError("unknown profile %r (throughput | latency)" % (profile,)) from None
+
+
+def set_thread_profile(profile):
+    """Profile of the free functions (MMCS commits) called on THIS thread from now on; objects carry their own."""
+    _lib.check(_lib.lib().p3hip_set_thread_profile(profile_kind(profile)))
+
+
+def get_thread_profile():
+    return {PROFILE_THROUGHPUT: "throughput", PROFILE_LATENCY: "latency"}.get(_lib.lib().p3hip_get_thread_profile())
+
+
 class FibAirProver:
     """prove(&config, &FibonacciAir{}, generate_trace_rows(a, b, 2^log_n), &[a, b, x]) (fib_air.rs:61-70)
     on the hip backend.  One instance = one HBM arena + one stream; use one per host thread."""
 
-    def __init__(self, log_n, log_blowup=1, params=None, own_stream=True, hash="poseidon2", hiding=False, seed=1):
+    def __init__(self, log_n, log_blowup=1, params=None, own_stream=True, hash="poseidon2", hiding=False, seed=1, profile="latency"):
         """hash="keccak": the reference's own hash configuration (fib_air.rs:28-53: Keccak MMCS +
         SerializingChallenger32 over a Keccak-256 HashChallenger).  hiding=True: the reference's MerkleTreeHidingMmcs +
-        HidingFriPcs with both SmallRng streams seeded by `seed` (fib_air.rs:40-65; wire format version 2)."""
+        HidingFriPcs with both SmallRng streams seeded by `seed` (fib_air.rs:40-65; wire format version 2).
+        profile (include/p3hip.h PROFILES), fixed at creation like the reference's backend (gpu_dft.rs:85-92): "latency" = one proof
+        at a time, what the reference does (the default, as p3hip_fib_prover_create*); "throughput" = this prover shares the chip
+        with others (bench.py's prover threads).  The proof bytes are the same."""
         self.params = params or FriParameters(log_blowup=log_blowup)
         self.log_n = log_n
         self.hash = hash
         self.hiding = hiding
+        self.profile = profile
         self._h = C.c_void_p()
         stream = None if own_stream else _stream_ptr()
-        if hiding:
-            _lib.check(_lib.lib().p3hip_fib_prover_create_hiding(_hash_kind(hash), log_n, C.cast(self.params._c(), C.c_void_p), seed,
-                                                                 stream, 1 if own_stream else 0, C.byref(self._h)))
-            return
-        _lib.check(_lib.lib().p3hip_fib_prover_create_hash(_hash_kind(hash), log_n, C.cast(self.params._c(), C.c_void_p),
-                                                           stream, 1 if own_stream else 0, C.byref(self._h)))
+        _lib.check(_lib.lib().p3hip_fib_prover_create_profile(profile_kind(profile), _hash_kind(hash), 1 if hiding else 0, seed if hiding else 0,
+                                                              log_n, C.cast(self.params._c(), C.c_void_p), stream, 1 if own_stream else 0,
+                                                              C.byref(self._h)))
 
     def prove(self, a, b):
         """Returns the proof bytes (wire format: DESIGN.md)."""

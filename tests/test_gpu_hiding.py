@@ -163,6 +163,21 @@ def test_hiding_bench_size_proof_bytes_equal_oracle_slow(p3, oracle):
         pytest.fail("proof words differ first at %d of %d" % (int(np.nonzero(w1 != w2)[0][0]), len(w1)))
 
 
+def test_hiding_prover_at_its_largest_domain(p3, oracle):
+    """The hiding prover admits LDE domains up to 2^24 points (log_n + 1 + log_blowup <= 24; prover.h MAX_LOG_DOMAIN_HIDING).  At
+    the bound — 2^22-row trace, randomized to 2^23, blowup 2, Keccak hashes — the oracle's verifier accepts the proof and rejects
+    another public value; one past the bound is refused at creation.  (Bytes against the oracle prover at 2^20 rows: the test above.)"""
+    gfp, ofp = _fp(p3, oracle, 1, 0, 20, 8)
+    pr = p3.FibAirProver(22, params=gfp, hash="keccak", hiding=True, seed=1)
+    proof = pr.prove(0, 1)
+    pr.close()
+    x = oracle.fib_public_x(0, 1, 1 << 22)
+    assert oracle.verify_fib_air_hiding(proof, 0, 1, x, 22, ofp, hash=oracle.HASH_KECCAK) == 0
+    assert oracle.verify_fib_air_hiding(proof, 0, 1, (x + 1) % 0x78000001, 22, ofp, hash=oracle.HASH_KECCAK) != 0
+    with pytest.raises(p3.P3HipError):
+        p3.FibAirProver(23, params=gfp, hash="keccak", hiding=True, seed=1)
+
+
 @pytest.mark.parametrize("log_n", [14, 15, 16, 17])
 def test_hiding_proof_bytes_where_the_narrow_plan_takes_over(p3, oracle, log_n):
     """Byte for byte against the oracle prover at the sizes where the hiding prover's transforms switch plans: the randomized

@@ -92,8 +92,8 @@ def test_keccak_config_proof_bytes_equal_the_oracle(p3, oracle, log_n, t):
 
 
 def test_keccak_config_headline_size(p3, oracle):
-    """2^20 rows, benchmark FRI parameters: the oracle's verifier accepts the GPU proof (the oracle prover would need
-    ~20 s here; equality of bytes is covered at the smaller sizes above)."""
+    """2^20 rows, benchmark FRI parameters, the reference's own hashes: the COMPLETE proof bytes equal the oracle prover's
+    (all host cores; until round 5 only bench.py's cpu_baseline leg compared them at this size), and the oracle's verifier accepts."""
     prover = p3.FibAirProver(20, hash="keccak")
     try:
         proof = prover.prove(0, 1)
@@ -102,6 +102,15 @@ def test_keccak_config_headline_size(p3, oracle):
         prover.close()
     x = oracle.fib_public_x(0, 1, 1 << 20)
     assert oracle.verify_fib_air(proof, 0, 1, x, 20, oracle.FriParams(), hash=oracle.HASH_KECCAK) == 0
+    oracle.set_threads(oracle.max_threads())
+    try:
+        ref = oracle.prove_fib_air(0, 1, 20, oracle.FriParams(), hash=oracle.HASH_KECCAK)
+    finally:
+        oracle.set_threads(1)
+    assert len(proof) == len(ref)
+    if proof != ref:
+        w1, w2 = np.frombuffer(proof, np.uint32), np.frombuffer(ref, np.uint32)
+        pytest.fail("cfg2 keccak: proof words differ first at %d of %d" % (int(np.nonzero(w1 != w2)[0][0]), len(w1)))
     assert p3.run_fib_air(hash="keccak") == "fib_air ok (n=8, x=21)"
 
 

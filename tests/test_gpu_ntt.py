@@ -248,6 +248,27 @@ def test_twelve_stage_digit_lde_host_and_device_paths(dft, oracle, p3, log_h, ab
         del dgot
 
 
+@pytest.mark.parametrize("log_h,ab", [(25, 1), (25, 2)])
+def test_lde_above_the_narrow_plan_2_25_rows(dft, oracle, p3, log_h, ab):
+    """2^25 rows x 2 leave the three-launch plan (ntt.hip lde_narrow: heights up to 2^24) for the general plan, at heights it had
+    never run before round 5: blowup 2 (2^26 output rows) and blowup 4 (2^27 rows = the field's two-adicity, the largest LDE the
+    entry point admits), element by element against the oracle (all host cores), through the device entry point."""
+    import torch
+    rng = np.random.default_rng(250000 + ab)
+    x = _rand(rng, 1 << log_h, 2)
+    oracle.set_threads(oracle.max_threads())
+    try:
+        exp = oracle.coset_lde_batch(x, ab, p3.GENERATOR_MONTY, True)
+    finally:
+        oracle.set_threads(1)
+    dgot = dft.coset_lde_batch(p3.dev_u32(x), ab, p3.GENERATOR_MONTY, bit_reversed_out=True)
+    torch.cuda.synchronize()
+    got = p3.host_u32(dgot)
+    del dgot
+    assert got.shape == exp.shape
+    assert np.array_equal(got, exp)
+
+
 @pytest.mark.parametrize("log_h,ab", [(16, 1), (17, 2), (18, 1), (19, 3), (20, 1), (21, 1), (22, 1)])
 def test_narrow_lde_of_six_columns(dft, oracle, p3, log_h, ab):
     """W = 6 — the hiding prover's randomized trace (2 trace columns + 4 random codewords, fib_air.rs:65) — through the narrow

@@ -1,46 +1,80 @@
-"""The kernel-path switches (environment variables read once per process) select code that the default configuration no
-longer reaches — e.g. the 16-lane cooperative Poseidon2 for layers of 2^12..2^15 digests, the one-state-per-lane Keccak
-levels everywhere, large cooperative chunks.  Each variant runs tests/variant_check.py in a child process: trees layer by
-layer and proofs byte for byte against the oracle."""
+"""Round 5 retired the experiment switches (41 environment variables, most of them selecting paths measured slower at every
+size: DESIGN.md section 4.3 lists them).  What is left to select is (a) the PROFILE — throughput | latency, fixed when a prover
+is created or set per thread for the free functions (include/p3hip.h PROFILES), so both run in ONE process here, byte for
+byte against the oracle (round 4: nineteen child processes) — and (b) two test-only switches read when a prover is created
+or proves (P3HIP_HIDING_PIECEWISE, P3HIP_GRIND_FIRST_LOG), set in-process by tests/test_gpu_hiding.py and tests/test_gpu_prover.py."""
 import os
-import subprocess
-import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-VARIANTS = [
-    {"P3HIP_COOP_MAX_LOG": "15", "P3HIP_COOP_CHUNK_LOG": "7"},          # round-1 shape: cooperative below 2^15, 128-digest chunks
-    {"P3HIP_COOP_MAX_LOG": "8", "P3HIP_COOP_CHUNK_LOG": "3"},
-    {"P3HIP_KECCAK_COOP_MAX_LOG": "0", "P3HIP_KECCAK_LANE_CHUNK_LOG": "11"},  # no cooperative Keccak, 2048-digest workgroups
-    {"P3HIP_KECCAK_COOP_MAX_LOG": "15", "P3HIP_KECCAK_COOP_CHUNK_LOG": "5"},
-    {"P3HIP_KECCAK_COOP_MAX_LOG": "12"},                                     # round 2's default
-    {"P3HIP_NTT_NARROW_COSSPLIT": "0", "P3HIP_NTT_FUSED": "0", "P3HIP_HIDING_PIECEWISE": "1"},
-    {"P3HIP_NTT_NARROW_F64": "0"},                                        # integer butterflies at every size
-    {"P3HIP_NTT_NARROW_F64": "7", "P3HIP_VARIANT_BIG_LDE": "1"},          # fp64 butterflies at every size, incl. 12-stage digits
-    {"P3HIP_NTT_NARROW_F64": "7", "P3HIP_NTT_NARROW_F64_TILES": "1", "P3HIP_NTT_NARROW_VW": "2"},
-    {"P3HIP_NTT_NARROW_F64": "5", "P3HIP_NTT_NARROW_F64_TILES": "2", "P3HIP_NTT_NARROW_VW": "1", "P3HIP_NTT_NARROW_COSSPLIT": "1"},
-    {"P3HIP_NTT_NARROW_F64": "7", "P3HIP_NTT_NARROW_F64_XW": "1", "P3HIP_VARIANT_BIG_LDE": "1"},  # fp64 rounds, hand-overs on words
-    {"P3HIP_RNG_TWO_PASS": "1", "P3HIP_LEAF_WIDE": "0", "P3HIP_HIDING_BARY_SPLIT": "1"},                    # first forms of the RNG fill and of the wide-row leaf kernel
-    {"P3HIP_NTT_NARROW_BLOCKED12": "0", "P3HIP_NTT_NARROW_K3_LQ1": "1", "P3HIP_NTT_NARROW_WIDE": "0", "P3HIP_VARIANT_BIG_LDE": "1"},
-    {"P3HIP_NTT_NARROW_BLOCKED12": "0", "P3HIP_VARIANT_CFG3_LDE": "1"},   # cfg3's LDE shape on the row-major intermediates
-    # round 4's switches: generic row-set leaf kernel for the salted leaves, four-launch RNG fill for small fills too, fills on the
-    # prover's own stream; RNG generation with four / two chunks per lane at sizes whose waves are then only partly filled
-    {"P3HIP_LEAF_SALTED": "0", "P3HIP_RNG_SMALL": "0", "P3HIP_HIDING_RNG_SIDE": "0"},
-    {"P3HIP_RNG_SUB_LOG": "2", "P3HIP_RNG_SMALL": "0"},
-    {"P3HIP_RNG_SUB_LOG": "1", "P3HIP_RNG_SMALL": "0"},
-    # the latency switches together: the FRI tail (layers of <= 2^7 rows) in one single-workgroup launch, the hiding prover's randomization
-    # commitment on a second side stream, one Poseidon2 state per DPP quad for layers of 2^12..2^15 digests
-    {"P3HIP_FRI_TAIL": "1", "P3HIP_HIDING_R_SIDE": "1", "P3HIP_Q4_MAX_LOG": "15"},
-    {"P3HIP_Q4_MAX_LOG": "14", "P3HIP_Q4_PRIO": "0", "P3HIP_COOP_MAX_LOG": "9"},
-]
+P = 0x78000001
 
 
-@pytest.mark.parametrize("env", VARIANTS, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
-def test_switch_variant_matches_oracle(env):
-    child_env = dict(os.environ, **env)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "variant_check.py")], env=child_env, cwd=ROOT,
-                       capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "variant ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+@pytest.mark.parametrize("profile", ["throughput", "latency"])
+def test_trees_under_both_thread_profiles(p3, oracle, profile):
+    """MMCS commits are free functions: they take the calling thread's profile.  Heights across every small-layer threshold
+    (cooperative below 2^12 / 2^10, quad Poseidon2 and cooperative Keccak up to 2^15 / 2^12 under the latency profile), single
+    and mixed-height matrix sets, and dense leaf rows of 9..64 words at 2^12..2^15 rows (the quad leaf kernel's multi-block
+    sponge: the advisor's round-4 finding) — digest layers equal the oracle's, layer by layer, for both hashes."""
+    rng = np.random.default_rng(11)
+    assert p3.get_thread_profile() == "latency"  # the default of a thread that has not chosen
+    p3.set_thread_profile(profile)
+    try:
+        assert p3.get_thread_profile() == profile
+        for hash_name, kind in (("poseidon2", oracle.HASH_POSEIDON2), ("keccak", oracle.HASH_KECCAK)):
+            shapes = [[(1 << 16, 2)], [(1 << 13, 3), (1 << 9, 5), (8, 2)], [(64, 9)], [(1 << 12, 9)], [(1 << 13, 17)], [(1 << 14, 33)],
+                      [(1 << 15, 64)], [(1 << 12, 8)], [(1 << 15, 2)], [(1 << 10, 4)], [(1 << 11, 4)]]
+            for dims in shapes:
+                mats = [rng.integers(0, P, d, dtype=np.uint32) for d in dims]
+                root, tree = p3.MerkleTreeMmcs(hash=hash_name).commit(mats)
+                oroot, otree = oracle.mmcs_commit(mats, kind)
+                assert np.array_equal(root, oroot), (profile, hash_name, dims)
+                for gl, ol in zip(tree.digest_layers(), otree.layers()):
+                    assert np.array_equal(gl, ol), (profile, hash_name, dims, len(gl))
+                tree.free()
+    finally:
+        p3.set_thread_profile("latency")
+    with pytest.raises(ValueError):
+        p3.set_thread_profile("fastest")
+
+
+def test_proofs_under_both_profiles_in_one_process(p3, oracle):
+    """A throughput prover and a latency prover side by side in one process (round 4 needed one child process per setting): the
+    same proof bytes as the oracle for both hashes, non-hiding and hiding; sizes whose FRI rounds are ALL tail (LDE of at most
+    2^8 rows), proofs with a final polynomial, blowup 4 and 8, and sizes whose trees cross the quad / cooperative thresholds."""
+    cases = [(1, (1, 0, 4, 2)), (3, (2, 2, 6, 5)), (6, (1, 0, 9, 5)), (7, (1, 3, 9, 0)), (9, (3, 1, 4, 10)), (10, (1, 0, 20, 8)),
+             (12, (2, 0, 10, 4)), (13, (1, 0, 10, 6)), (15, (1, 0, 8, 5))]
+    for hash_name, kind in (("poseidon2", oracle.HASH_POSEIDON2), ("keccak", oracle.HASH_KECCAK)):
+        for log_n, t in cases:
+            ref = oracle.prove_fib_air(3, 5, log_n, oracle.FriParams(*t), hash=kind)
+            provers = [p3.FibAirProver(log_n, params=p3.FriParameters(*t), hash=hash_name, profile=pf) for pf in ("throughput", "latency")]
+            for pr in provers:
+                assert pr.prove(3, 5) == ref, (hash_name, log_n, t, pr.profile)
+            for pr in provers:
+                assert pr.prove(3, 5) == ref, (hash_name, log_n, t, pr.profile, "second proof")
+                pr.close()
+    for hash_name, kind in (("poseidon2", oracle.HASH_POSEIDON2), ("keccak", oracle.HASH_KECCAK)):
+        for log_n, t in [(3, (2, 2, 2, 1)), (9, (1, 0, 8, 4)), (13, (1, 0, 6, 4))]:
+            ref = oracle.prove_fib_air_hiding(0, 1, log_n, oracle.FriParams(*t), hash=kind, seed=1)
+            for pf in ("throughput", "latency"):
+                pr = p3.FibAirProver(log_n, params=p3.FriParameters(*t), hash=hash_name, hiding=True, seed=1, profile=pf)
+                assert pr.prove(0, 1) == ref and pr.prove(0, 1) == ref, (hash_name, log_n, t, pf, "hiding")
+                pr.close()
+    with pytest.raises(ValueError):
+        p3.FibAirProver(5, profile="fastest")
+
+
+def test_pool_of_one_is_a_lone_prover(p3, oracle):
+    """p3hip_fib_batch_create*: a pool of more than one prover runs the throughput profile, a pool of ONE the latency profile;
+    the bytes are the oracle's either way."""
+    t = (1, 0, 12, 5)
+    ref = [oracle.prove_fib_air(a, a + 1, 13, oracle.FriParams(*t)) for a in range(3)]
+    for n_provers in (1, 3):
+        pool = p3.FibAirBatchProver(13, n_provers=n_provers, params=p3.FriParameters(*t))
+        try:
+            assert pool.prove([(a, a + 1) for a in range(3)]) == ref, n_provers
+        finally:
+            pool.close()

@@ -47,22 +47,39 @@ def test_reference_instance(p3, oracle):
     assert oracle.verify_fib_air(proof, 0, 1, 22, 3, ofp) != 0
 
 
-def test_headline_2_20_verifies_and_matches_commitments(p3, oracle):
-    """BASELINE cfg2 (2^20 rows, blowup 2, benchmark FRI parameters).  The full oracle proof takes ~20 s of
-    CPU; here: the oracle VERIFIER accepts the GPU proof, and the trace commitment inside the proof equals the
-    oracle's commitment of the same trace (bench.py's cpu_baseline leg compares the complete bytes)."""
+def _assert_same_proof(proof, ref, what):
+    assert len(proof) == len(ref), (what, len(proof), len(ref))
+    if proof != ref:
+        w1, w2 = np.frombuffer(proof, np.uint32), np.frombuffer(ref, np.uint32)
+        first = int(np.nonzero(w1 != w2)[0][0])
+        pytest.fail("%s: proof words differ first at %d of %d" % (what, first, len(w1)))
+
+
+def test_headline_2_20_proof_bytes_equal_oracle(p3, oracle):
+    """BASELINE cfg2 at its own size (2^20 rows, blowup 2, the benchmark's FRI parameters: 100 queries, 16 proof-of-work bits):
+    the COMPLETE proof bytes equal the oracle prover's (run on every host core: field arithmetic is exact, the bytes do not
+    depend on the thread count — tests/test_oracle_stark.py), the oracle verifier accepts them, arena reuse is clean, the
+    trace commitment inside the proof is the oracle's commitment of the same trace.  Until round 5 this comparison lived
+    only in bench.py's cpu_baseline leg."""
     gfp, ofp = _fp(p3, oracle, 1, 0, 100, 16)
     pr = p3.FibAirProver(20, params=gfp)
     proof = pr.prove(0, 1)
     x = oracle.fib_public_x(0, 1, 1 << 20)
+    oracle.set_threads(oracle.max_threads())
+    try:
+        ref = oracle.prove_fib_air(0, 1, 20, ofp)
+        lde = oracle.coset_lde_batch(oracle.generate_trace_rows(0, 1, 1 << 20), 1, p3.GENERATOR_MONTY, True)
+        root, _ = oracle.mmcs_commit([lde])
+    finally:
+        oracle.set_threads(1)
+    _assert_same_proof(proof, ref, "cfg2 poseidon2")
     assert oracle.verify_fib_air(proof, 0, 1, x, 20, ofp) == 0
     assert pr.prove(0, 1) == proof  # arena reuse is clean
     words = np.frombuffer(proof, np.uint32)
-    lde = oracle.coset_lde_batch(oracle.generate_trace_rows(0, 1, 1 << 20), 1, p3.GENERATOR_MONTY, True)
-    root, _ = oracle.mmcs_commit([lde])
     assert np.array_equal(words[3:11], root)
     other = pr.prove(1, 2)
     assert other != proof and oracle.verify_fib_air(other, 1, 2, oracle.fib_public_x(1, 2, 1 << 20), 20, ofp) == 0
+    pr.close()
 
 
 def test_concurrent_provers_on_threads(p3, oracle):
@@ -164,19 +181,51 @@ def test_bad_parameters(p3, oracle):
         oracle.prove_fib_air(0, 1, 9, oracle.FriParams(1, 9, 3, 2))
     with pytest.raises(p3.P3HipError):
         p3.FibAirProver(27, params=p3.FriParameters(log_blowup=2))
+    with pytest.raises(p3.P3HipError):
+        p3.FibAirProver(26, params=p3.FriParameters(log_blowup=1))  # 2^27-point domain: above the tested bound (2^26)
 
 
-def test_cfg3_2_24_blowup4_verifies(p3, oracle):
-    """BASELINE configs[2]: 2^24-row trace, blowup 4 ("FRI-fold-heavy").  A CPU oracle proof of this size takes
-    minutes, so parity here is the size-independent property: the oracle's verifier accepts the GPU proof and
-    rejects it for a different public value."""
-    gfp, ofp = _fp(p3, oracle, 2, 0, 50, 8)
+def test_cfg3_2_24_blowup4_proof_bytes_equal_oracle(p3, oracle):
+    """BASELINE configs[2] at its own size AND with bench.py's parameters (2^24-row trace, blowup 4, 100 queries, 16
+    proof-of-work bits — "FRI-fold-heavy"): the complete proof bytes equal the oracle prover's.  Every commitment is in those
+    bytes: the trace root over the 2^26-leaf tree, the quotient root (quotient at blowup 4), the 24 FRI layer roots (the
+    2^26-point folds), plus opened values, witness and all 100 query openings.  The oracle proof runs on every host core
+    (~1-3 min on the GPU box's 16; ~15 GB of host memory) — the single most expensive test of the suite, which is why the
+    smaller parameter set (50 queries, 8 bits) it replaced was accept / reject only.  Also: the oracle verifier accepts, and
+    rejects another public value."""
+    gfp, ofp = _fp(p3, oracle, 2, 0, 100, 16)
     pr = p3.FibAirProver(24, params=gfp)
     proof = pr.prove(0, 1)
+    pr.close()
     x = oracle.fib_public_x(0, 1, 1 << 24)
     assert oracle.verify_fib_air(proof, 0, 1, x, 24, ofp) == 0
     assert oracle.verify_fib_air(proof, 0, 1, x + 1, 24, ofp) != 0
+    oracle.set_threads(oracle.max_threads())
+    try:
+        ref = oracle.prove_fib_air(0, 1, 24, ofp)
+    finally:
+        oracle.set_threads(1)
+    words, rwords = np.frombuffer(proof, np.uint32), np.frombuffer(ref, np.uint32)
+    assert np.array_equal(words[3:11], rwords[3:11]), "cfg3: trace commitment differs from the oracle's"
+    assert np.array_equal(words[11:19], rwords[11:19]), "cfg3: quotient commitment differs from the oracle's"
+    _assert_same_proof(proof, ref, "cfg3")
+
+
+def test_largest_domain_the_prover_admits(p3, oracle):
+    """The prover admits LDE domains up to 2^26 points (log_n + log_blowup <= 26: BASELINE configs[2]'s size, the largest
+    any test or bench has run; until round 5 the bound was the field's two-adicity, 27, which nothing had ever exercised).
+    At the bound with the OTHER split (2^25 rows, blowup 2): the oracle verifier accepts; one past it is refused at creation."""
+    gfp, ofp = _fp(p3, oracle, 1, 0, 30, 8)
+    pr = p3.FibAirProver(25, params=gfp)
+    proof = pr.prove(2, 5)
     pr.close()
+    x = oracle.fib_public_x(2, 5, 1 << 25)
+    assert oracle.verify_fib_air(proof, 2, 5, x, 25, ofp) == 0
+    assert oracle.verify_fib_air(proof, 2, 5, x + 1, 25, ofp) != 0
+    with pytest.raises(p3.P3HipError):
+        p3.FibAirProver(26, params=gfp)
+    with pytest.raises(p3.P3HipError):
+        p3.FibAirProver(25, params=p3.FriParameters(2, 0, 30, 8))
 
 
 def test_dft_benchmark_harness(p3, oracle):

@@ -456,7 +456,7 @@ def run(args, job, dist, world, rank, local_rank, n_dev, backend, coll_dev, use_
         run starts.  It is issued inside the timed region (run_steps), on the collective stream, and nothing blocks on it: the first
         issue() waits for the event behind its pinned landing copy."""
         steps = [[(k * n_total + i, k * n_total + i + 1) for i in range(n_total)] for k in range(first, first + count)] if rank == 0 else []
-        coll_state["descriptors"] = timed("scatter_wait_s", lambda: pbatch.scatter_descriptor_steps(steps, device=coll_dev, shape=(count, n_total)))
+        coll_state["descriptors"] = timed("scatter_wait_s", lambda: coll_state["scatterer"].run(steps))
         coll_state["descriptors_first"] = first
         coll_state["scatters"] = coll_state.get("scatters", 0) + 1
 
@@ -478,6 +478,8 @@ def run(args, job, dist, world, rank, local_rank, n_dev, backend, coll_dev, use_
             dist.all_reduce(width, op=dist.ReduceOp.MAX)  # proofs of one parameter set have one length: the slot width
             coll_state["width"] = int(width.item())
             coll_state["gatherer"] = pbatch.ProofGatherer(n_total, coll_dev)
+            # every buffer of the run's one scatter exists before the timed region starts
+            coll_state["scatterer"] = pbatch.DescriptorScatter(max(args.steps, args.warmup, 1), n_total, coll_dev)
         except Exception as e:
             print("bench.py: collective setup failed on rank %d: %r" % (rank, e), file=sys.stderr)
             if not allow_local:
@@ -602,6 +604,8 @@ def run(args, job, dist, world, rank, local_rank, n_dev, backend, coll_dev, use_
                       "host_core_list and pinning are rank 0's (every rank applies the same rule to its own GPU)",
         "gather_bytes_per_step": (n_total * coll_state["width"]) if use_gather and "width" in coll_state else 0,
         "descriptor_scatters_in_timed_region": (1 if args.steps > 0 else 0) if use_gather else 0,
+        "descriptor_scatter_host_ms": ({k: round(v, 3) for k, v in coll_state["scatterer"].last_ms.items()}
+                                       if use_gather and "scatterer" in coll_state else None),
         "parity": "proof bytes / digests are compared with the repo's C oracle (a restatement of upstream Plonky3 from "
                   "recall; pinned by reference code only for the DFT): self-consistent, upstream parity UNPINNED",
     }

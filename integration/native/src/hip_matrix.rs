@@ -183,45 +183,125 @@ impl<F: Field> Matrix<F> for HipMatrix<F> {
         // the host copy has the layout of the device words, and the pair is remembered for `HipMmcs::commit`
         let host = self.download();
         if self.order == RowOrder::Natural {
-            register_resident(host.values.as_ptr() as usize, host.values.len(), self.buf.clone());
+            register_resident(host.values.as_ptr() as usize, host.values.len(), fingerprint_of(&host), self.buf.clone());
         }
         host
     }
 }
 
 // ---- residency registry: host address of a dense matrix's words -> the HBM allocation holding the same words ----
-// Bounded (the last 8 downloads; a prover commits each LDE right after producing it), entries are taken on use.  The host
-// words are not mutated between the download and the commit (the Vec is moved into the RowMajorMatrix the PCS commits), and a
-// hit is checked by length as well as by address.
+// Bounded (the last 8 downloads; a prover commits each LDE right after producing it).  An address alone proves nothing: if the
+// RowMajorMatrix that `to_row_major_matrix` returned is dropped or mutated before the commit, the allocator readily hands the same
+// address to the next Vec of the same size, and a later, unrelated matrix would hit the stale entry — the tree would be built over
+// the OLD device words while the tree's host rows are the new ones (round-4 advisor finding).  So a hit must be VERIFIED:
+//   * every entry carries a 64-bit fingerprint of the matrix it was registered with (`fingerprint_of`: dimensions, the first and
+//     last 16 elements and 64 strided samples, FNV-1a over their canonical values, read through the `Matrix` trait — so it can be
+//     recomputed for ANY matrix type the commit is handed, without assuming its memory layout); a reused address with other
+//     contents misses;
+//   * under `cfg(debug_assertions)` `HipMmcs::commit` downloads the device copy and compares it in full (`debug_same_words`),
+//     like the dft self-check of backend_hip.rs;
+//   * looking up does not consume: `take_residents` removes entries only when EVERY input of the commit matched, so a commit with a
+//     mix of resident and foreign inputs leaves the registry as it was.
+pub struct ResidentQuery {
+    pub host_addr: usize,
+    pub len: usize,
+    pub fingerprint: u64,
+}
 struct Resident {
     host_addr: usize,
     len: usize,
+    fingerprint: u64,
     buf: Arc<DeviceBuf>,
+}
+/// Sampled content hash of a matrix, through the trait's accessors only.
+pub fn fingerprint_of<F: Field, M: Matrix<F>>(m: &M) -> u64 {
+    const OFFSET: u64 = 0xcbf2_9ce4_8422_2325;
+    const PRIME: u64 = 0x0000_0100_0000_01b3;
+    let (h, w) = (m.height(), m.width());
+    let n = h * w;
+    let mut acc = OFFSET ^ (h as u64) ^ ((w as u64) << 40);
+    let mut eat = |i: usize| {
+        // element i of the row-major order; hashed through its Debug-independent bytes: BabyBear is repr(transparent) over its
+        // Montgomery u32 (backend_vulkan.rs:2002-2005), read here without assuming how the MATRIX stores it
+        let e: F = unsafe { m.get_unchecked(i / w, i % w) };
+        let word: u32 = unsafe { core::mem::transmute_copy::<F, u32>(&e) };
+        for b in word.to_le_bytes() {
+            acc = (acc ^ b as u64).wrapping_mul(PRIME);
+        }
+    };
+    if n == 0 {
+        return acc;
+    }
+    for i in 0..n.min(16) {
+        eat(i);
+    }
+    for i in n.saturating_sub(16)..n {
+        eat(i);
+    }
+    if n > 32 {
+        let step = (n / 64).max(1);
+        let mut i = step / 2;
+        while i < n {
+            eat(i);
+            i += step;
+        }
+    }
+    acc
 }
 fn registry() -> &'static Mutex<VecDeque<Resident>> {
     static R: OnceLock<Mutex<VecDeque<Resident>>> = OnceLock::new();
     R.get_or_init(|| Mutex::new(VecDeque::new()))
 }
-fn register_resident(host_addr: usize, len: usize, buf: Arc<DeviceBuf>) {
+fn register_resident(host_addr: usize, len: usize, fingerprint: u64, buf: Arc<DeviceBuf>) {
     if let Ok(mut q) = registry().lock() {
+        // one entry per address: a newer matrix at the same address replaces the older one
+        q.retain(|r| r.host_addr != host_addr);
         if q.len() == 8 {
             q.pop_front();
         }
-        q.push_back(Resident { host_addr, len, buf });
+        q.push_back(Resident { host_addr, len, fingerprint, buf });
     }
 }
-/// The device copy of the dense matrix whose words start at `host_addr`, if `HipMatrix::to_row_major_matrix` produced it.
-/// The returned guard keeps the allocation alive (hand it to the tree that is built over it).
+/// The device copy of a dense host matrix that `HipMatrix::to_row_major_matrix` produced.
+/// The guard keeps the allocation alive (hand it to the tree that is built over it).
 pub struct ResidentWords(Arc<DeviceBuf>);
 impl ResidentWords {
     pub fn device_ptr(&self) -> *const u32 {
         self.0.ptr as *const u32
     }
+    /// Debug builds: the device words equal the matrix's, element by element (one extra download per commitment).
+    pub fn debug_same_words<F: Field, M: Matrix<F>>(&self, m: &M) -> bool {
+        let n = m.height() * m.width();
+        let mut dev = vec![0u32; n];
+        if unsafe { p3hip_download(dev.as_mut_ptr() as *mut c_void, self.0.ptr, n * 4) } != 0 {
+            return false;
+        }
+        let w = m.width().max(1);
+        (0..n).all(|i| {
+            let e: F = unsafe { m.get_unchecked(i / w, i % w) };
+            dev[i] == unsafe { core::mem::transmute_copy::<F, u32>(&e) }
+        })
+    }
 }
-pub fn take_resident(host_addr: usize, len: usize) -> Option<ResidentWords> {
+/// Takes the entries of ALL the queried matrices, or none: `None` unless every query has an entry with the same address, length
+/// and fingerprint (and no two queries name the same entry).
+pub fn take_residents(all: &[ResidentQuery]) -> Option<Vec<ResidentWords>> {
     let mut q = registry().lock().ok()?;
-    let i = q.iter().position(|r| r.host_addr == host_addr && r.len == len)?;
-    q.remove(i).map(|r| ResidentWords(r.buf))
+    let mut idx = Vec::with_capacity(all.len());
+    for want in all {
+        let i = q.iter().position(|r| r.host_addr == want.host_addr && r.len == want.len && r.fingerprint == want.fingerprint)?;
+        if idx.contains(&i) {
+            return None;
+        }
+        idx.push(i);
+    }
+    let out: Vec<ResidentWords> = idx.iter().map(|&i| ResidentWords(q[i].buf.clone())).collect();
+    let mut sorted = idx;
+    sorted.sort_unstable_by(|a, b| b.cmp(a)); // highest index first: the others keep their places
+    for i in sorted {
+        q.remove(i);
+    }
+    Some(out)
 }
 
 // ---- what GpuDft returns: host matrices from the cpu / vulkan / metal / webgpu arms, device matrices from the hip arm ----

@@ -168,16 +168,32 @@ where
         // over after GpuDft's hip arm produced the LDE) still has its device copy registered under the address of its words.
         // `row_slice(0)` of a dense matrix derefs into those words; of any other matrix type into a temporary, which is simply
         // not in the registry.  When EVERY input is resident the tree is built over the device copies: no upload at all.
-        let resident: Vec<crate::hip_matrix::ResidentWords> = inputs
+        // A hit is VERIFIED — address, length and a sampled fingerprint read through the Matrix trait (hip_matrix.rs `fingerprint_of`),
+        // plus a full compare against the device words in debug builds — and the registry is only touched when EVERY input matched
+        // (`take_residents`): a stale entry at a reused address, or a mix of resident and foreign inputs, takes the upload path below.
+        let queries: Vec<crate::hip_matrix::ResidentQuery> = inputs
             .iter()
-            .filter_map(|m| {
-                if m.height() == 0 {
-                    return None;
-                }
+            .filter(|m| m.height() > 0)
+            .map(|m| {
                 let first = m.row_slice(0);
-                crate::hip_matrix::take_resident(first.as_ptr() as usize, m.height() * m.width())
+                crate::hip_matrix::ResidentQuery {
+                    host_addr: first.as_ptr() as usize,
+                    len: m.height() * m.width(),
+                    fingerprint: crate::hip_matrix::fingerprint_of(m),
+                }
             })
             .collect();
+        let mut resident: Vec<crate::hip_matrix::ResidentWords> = if queries.len() == inputs.len() {
+            crate::hip_matrix::take_residents(&queries).unwrap_or_default()
+        } else {
+            Vec::new()
+        };
+        #[cfg(debug_assertions)]
+        {
+            if resident.len() == inputs.len() && !resident.iter().zip(inputs.iter()).all(|(r, m)| r.debug_same_words(m)) {
+                resident.clear(); // fingerprint collision or a mutated host copy: commit what the caller actually handed over
+            }
+        }
         if resident.len() == inputs.len() {
             let ptrs: Vec<*const u32> = resident.iter().map(|r| r.device_ptr()).collect();
             let rc = unsafe {

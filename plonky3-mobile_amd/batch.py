@@ -106,39 +106,92 @@ class PendingDescriptors:
         return self._steps
 
 
+class DescriptorScatter:
+    """The scatter of a run's descriptors with every buffer allocated up front (pinned host table, device send / receive buffers,
+    pinned landing buffer): run() then costs one table fill, one H2D copy, ONE scatter and one D2H copy, all enqueued on the
+    collective stream — no allocation and no pinned-memory registration inside a timed region."""
+
+    def __init__(self, max_steps, n, device="cpu"):
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.device, self.stream = str(device), collective_stream(device)
+        self.max_steps, self.n = max_steps, n
+        self.per = (n + self.world - 1) // self.world
+        rows = max(max_steps * self.per, 1)
+        gpu = self.stream is not None
+        self.recv_host = torch.full((rows, 3), -1, dtype=torch.int64)
+        if gpu:
+            self.recv_host = self.recv_host.pin_memory()
+            self.recv_dev = torch.full((rows, 3), -1, dtype=torch.int64, device=device)
+            self.event = torch.cuda.Event()
+        if self.rank == 0:
+            self.table = torch.full((self.world, rows, 3), -1, dtype=torch.int64)
+            if gpu:
+                self.table = self.table.pin_memory()
+                self.table_dev = torch.empty((self.world, rows, 3), dtype=torch.int64, device=device)
+        self.last_ms = {}
+
+    def run(self, steps):
+        """steps (rank 0; ignored elsewhere): one list of instances (a, b) per step, at most max_steps of at most n.  Returns
+        PendingDescriptors; nothing blocks."""
+        import time
+        t0 = time.perf_counter()
+        n_steps = len(steps) if self.rank == 0 else None
+        if self.rank == 0:
+            if n_steps > self.max_steps or any(len(s) > self.n for s in steps):
+                raise ValueError("scatter_descriptor_steps: %d steps of at most %d instances announced, got %r" % (self.max_steps, self.n, [len(s) for s in steps]))
+            tab = self.table.numpy()
+            tab[:] = -1
+            for k, inst in enumerate(steps):
+                arr = np.asarray(inst, dtype=np.int64).reshape(len(inst), 2)
+                for r in range(self.world):
+                    idx = np.arange(r, len(inst), self.world, dtype=np.int64)
+                    tab[r, k * self.per:k * self.per + len(idx), 0] = idx
+                    tab[r, k * self.per:k * self.per + len(idx), 1:] = arr[idx]
+        t1 = time.perf_counter()
+        if self.stream is None:
+            dist.scatter(self.recv_host, [self.table[r] for r in range(self.world)] if self.rank == 0 else None, src=0)
+            self.last_ms = {"fill": 1e3 * (t1 - t0), "issue": 1e3 * (time.perf_counter() - t1)}
+            return PendingDescriptors(self.recv_host, self.max_steps, self.per)
+        with torch.cuda.stream(self.stream):
+            if self.rank == 0:
+                self.table_dev.copy_(self.table, non_blocking=True)
+                dist.scatter(self.recv_dev, [self.table_dev[r] for r in range(self.world)], src=0)
+            else:
+                dist.scatter(self.recv_dev, None, src=0)
+            self.recv_host.copy_(self.recv_dev, non_blocking=True)
+            self.event.record(self.stream)
+        self.last_ms = {"fill": 1e3 * (t1 - t0), "issue": 1e3 * (time.perf_counter() - t1)}
+        return PendingDescriptors(_Landed(self.recv_host, self.event), self.max_steps, self.per)
+
+
+class _Landed:
+    def __init__(self, host, event):
+        self.host, self.event = host, event
+
+    def tolist(self):
+        self.event.synchronize()
+        return self.host.tolist()
+
+
 def scatter_descriptor_steps(steps, device="cpu", shape=None):
     """`steps` (rank 0 only; anything on the other ranks): a list with one list of instances (a, b) per step.  ONE scatter moves
     every step's descriptors; rank r receives, for each step, the instances shard_instances(n, r, world) of that step.
-    `shape` = (number of steps, instances per step) when every rank knows it (bench.py does: nothing but the scatter is
-    issued then, and nothing blocks); without it rank 0's shape is broadcast first.  Returns PendingDescriptors."""
-    world, rank = dist.get_world_size(), dist.get_rank()
+    `shape` = (number of steps, instances per step) when every rank knows it (nothing but the scatter is issued then);
+    without it rank 0's shape is broadcast first.  Returns PendingDescriptors.  (A caller that scatters inside a timed region
+    keeps a DescriptorScatter instead: this convenience form allocates its buffers per call.)"""
+    rank = dist.get_rank()
     stream = collective_stream(device)
-    with _on(stream):
-        if shape is None:
+    if shape is None:
+        with _on(stream):
             t = torch.tensor([len(steps), max([len(s) for s in steps], default=0)] if rank == 0 else [0, 0], dtype=torch.int64)
             if stream is not None:
                 t = t.pin_memory().to(device, non_blocking=True)
             dist.broadcast(t, 0)
             shape = (_Landing(t, stream).tolist() if stream is not None else t.tolist())
-        n_steps, n = int(shape[0]), int(shape[1])
-        if rank == 0 and (len(steps) != n_steps or any(len(s) > n for s in steps)):
-            raise ValueError("scatter_descriptor_steps: %d steps of at most %d instances announced, got %r" % (n_steps, n, [len(s) for s in steps]))
-        per = (n + world - 1) // world
-        recv = torch.full((max(n_steps * per, 1), 3), -1, dtype=torch.int64, device=device)
-        if rank == 0:
-            table = np.full((world, max(n_steps * per, 1), 3), -1, dtype=np.int64)
-            for k, inst in enumerate(steps):
-                for r in range(world):
-                    for j, i in enumerate(shard_instances(len(inst), r, world)):
-                        table[r, k * per + j] = (i, inst[i][0], inst[i][1])
-            host = torch.from_numpy(table)
-            if stream is not None:
-                host = host.pin_memory().to(device, non_blocking=True)
-            dist.scatter(recv, [host[r] for r in range(world)], src=0)
-        else:
-            dist.scatter(recv, None, src=0)
-        landing = _Landing(recv, stream) if stream is not None else recv
-    return PendingDescriptors(landing, n_steps, per)
+    n_steps, n = int(shape[0]), int(shape[1])
+    if rank == 0 and (len(steps) != n_steps or any(len(s) > n for s in steps)):
+        raise ValueError("scatter_descriptor_steps: %d steps of at most %d instances announced, got %r" % (n_steps, n, [len(s) for s in steps]))
+    return DescriptorScatter(n_steps, n, device).run(steps)
 
 
 def scatter_descriptors(instances, device="cpu"):

@@ -94,13 +94,16 @@ def test_trait_path_keeps_the_lde_resident_and_carries_the_debug_self_check():
     src = os.path.join(INTEG, "native", "src")
     mat = open(os.path.join(src, "hip_matrix.rs")).read()
     for needle in ("pub struct HipMatrix<F>", "impl<F: Field> Matrix<F> for HipMatrix<F>", "impl<F: Field> BitReversibleMatrix<F> for HipMatrix<F>",
-                   "pub enum GpuEvaluations<F>", "pub fn take_resident(", "register_resident(", "RowOrder::BitReversed", "p3hip_download("):
+                   "pub enum GpuEvaluations<F>", "pub fn take_residents(", "register_resident(", "RowOrder::BitReversed", "p3hip_download(",
+                   # round-4 advisor finding: a registry hit is verified (fingerprint through the Matrix trait, full compare in debug builds)
+                   "pub fn fingerprint_of<", "r.fingerprint == want.fingerprint", "pub fn debug_same_words<"):
         assert needle in mat, needle
     patch = open(os.path.join(src, "gpu_dft.rs.patch")).read()
     assert "type Evaluations = GpuEvaluations<F>;" in patch and "-    type Evaluations = RowMajorMatrix<F>;" in patch
     assert "backend_hip::coset_lde_batch_resident(" in patch and "GpuEvaluations::Device(result)" in patch
     mmcs = open(os.path.join(src, "hip_mmcs.rs")).read()
-    assert "crate::hip_matrix::take_resident(" in mmcs and "p3hip_mmcs_commit_hash_dev(" in mmcs
+    assert "crate::hip_matrix::take_residents(" in mmcs and "p3hip_mmcs_commit_hash_dev(" in mmcs
+    assert "crate::hip_matrix::fingerprint_of(m)" in mmcs and "debug_same_words(m)" in mmcs  # entries leave the registry only when ALL inputs matched
     hip = open(os.path.join(src, "backend_hip.rs")).read()
     assert "#[cfg(debug_assertions)]" in hip and "cpu.dft_batch(input)" in hip and "bit_reverse_rows()" in hip
     assert "p3hip_coset_lde_batch_bb31_dev(" in hip and "RowOrder::BitReversed" in hip

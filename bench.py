@@ -163,7 +163,8 @@ def other_workloads(budget_s=240.0, child_timeout_s=120.0):
                               "lde_us": rnd(r.get("avg_us"), 1), "lde_gbps": rnd(r.get("achieved"), 1), "lde_frac": rnd(r.get("frac")),
                               "lde_valu_frac": rnd(r.get("valu_frac")), "lde_traffic": r.get("traffic")})
                 if v:
-                    entry.update({"hash_valu_busy": rnd(v.get("frac")), "sustained_gperm_s": rnd(v.get("sustained_gperm_s"), 3),
+                    entry.update({"proof_valu_issue_frac": rnd(v.get("frac")), "valu_M_instr_per_proof": rnd((v.get("valu_wave_instr_per_proof") or 0) / 1e6, 1) or None,
+                                  "sustained_gperm_s": rnd(v.get("sustained_gperm_s"), 3),
                                   "sustained_frac_of_kernel_ceiling": rnd(v.get("sustained_frac_of_kernel_ceiling"))})
                 if "commit" in r:
                     entry["commit_gperm_s"] = rnd(r["commit"].get("gperm_s"), 3)
@@ -611,8 +612,14 @@ def run(args, job, dist, world, rank, local_rank, n_dev, backend, coll_dev, use_
     }
     out.update(job.extra_report())
     vr = out.get("valu_roofline")
+    if isinstance(vr, dict) and vr.get("valu_wave_instr_per_proof"):
+        # the ruler that binds: what the timed region issued, in VALU wave-instructions per second, against the chip's measured issue peak
+        vr["achieved"] = value * vr["valu_wave_instr_per_proof"] / 1e9 / world
+        vr["frac"] = vr["achieved"] / vr["peak"]
+        vr["proof_valu_issue_frac"] = vr["frac"]
+        vr["achieved_is"] = "proofs/s of the timed region x VALU wave-instructions per proof (PMC), per GPU"
     if isinstance(vr, dict) and vr.get("permutations_per_proof"):
-        # what the timed region sustained, in the hash kernels' own unit: proofs/s x permutations per proof
+        # the same in the hash kernels' own unit: proofs/s x permutations per proof (counts the hash layers only: 78-97 % of the instructions)
         vr["sustained_gperm_s"] = value * vr["permutations_per_proof"] / 1e9
         ceiling = vr.get("kernel_ceiling_gperm_s")
         if ceiling:

@@ -140,6 +140,20 @@ def lib():
     return _lib
 
 
+_sha = None
+
+
+def lib_sha256():
+    """SHA-256 of the libp3hip.so this process loads: the build identity the committed PMC profiles are keyed by (a counter
+    figure divided by a time measured in this run describes this run only if both come from the same code)."""
+    global _sha
+    if _sha is None:
+        import hashlib
+        with open(LIB_PATH, "rb") as f:
+            _sha = hashlib.sha256(f.read()).hexdigest()
+    return _sha
+
+
 def declared_symbols():
     return sorted(_SIGS)
 

@@ -18,17 +18,38 @@ from .gpu_dft import GENERATOR_MONTY, BackendKind, GpuDft, _stream_ptr
 from .mmcs import MerkleTreeMmcs
 
 
-def lde_valu_view(key, unit_us, algorithmic_bytes):
-    """The coset-LDE unit against the roofline that actually binds it from ~2^21 rows on: VALU issue.  `key` = cfg2 | cfg3 | cfg5 in
-    profiles/r04_pmc_lde_valu.json (SQ_INSTS_VALU of the unit's launches, tools/r04_lde_valu.sh).  valu_frac = wave-instructions of
-    the unit / measured unit time / the chip's measured issue rate (36 T lane-ops/s = 562.5 G wave-instructions/s,
-    profiles/r01_microbench2_valu_issue_rates.txt); hbm_frac_ceiling_at_this_instruction_count = the best HBM fraction this many
-    instructions allow, i.e. algorithmic bytes / (instructions / issue rate) / 8 TB/s."""
+def _profile_json(names):
+    """First readable profiles/<name> of `names` -> (name, parsed, stale): stale = the file records the SHA-256 of the libp3hip.so
+    it was measured on and the library loaded now is another build (round-4 advisor finding: a checked-in instruction count
+    divided by a time measured in this run was presented as a measurement of this run whatever the code had become)."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name in names:
+        try:
+            with open(os.path.join(root, "profiles", name)) as f:
+                pmc = json.load(f)
+        except Exception:
+            continue
+        sha = pmc.get("lib_sha256")
+        return name, pmc, (None if sha is None else sha != _lib.lib_sha256())
+    return None, None, None
+
+
+def _stale_note(stale):
+    return {None: "the profile predates build identities (round 4 or earlier): may describe older kernels",
+            True: "STALE: the profile was measured on another build of libp3hip.so than the one loaded now",
+            False: "same build: the profile's lib_sha256 equals the loaded library's"}[stale]
+
+
+def lde_valu_view(key, unit_us, algorithmic_bytes):
+    """The coset-LDE unit against the roofline that actually binds it from ~2^21 rows on: VALU issue.  `key` = cfg2 | cfg3 | cfg5 in
+    profiles/r05_pmc_lde_valu.json (SQ_INSTS_VALU of the unit's launches, tools/r05_lde_valu.sh; round 4's file as a fallback).
+    valu_frac = wave-instructions of the unit / measured unit time / the chip's measured issue rate (36 T lane-ops/s = 562.5 G
+    wave-instructions/s, profiles/r01_microbench2_valu_issue_rates.txt); hbm_frac_ceiling_at_this_instruction_count = the best HBM
+    fraction this many instructions allow, i.e. algorithmic bytes / (instructions / issue rate) / 8 TB/s.  `valu_profile_build` says
+    whether the counts come from the library that is loaded now."""
     try:
-        with open(os.path.join(root, "profiles", "r04_pmc_lde_valu.json")) as f:
-            pmc = json.load(f)
+        name, pmc, stale = _profile_json(("r05_pmc_lde_valu.json", "r04_pmc_lde_valu.json"))
         e = pmc[key]
         peak = pmc.get("peak_wave_instr_per_s", 36e12 / 64)
         wi = e["unit_valu_wave_instr"]
@@ -37,9 +58,24 @@ def lde_valu_view(key, unit_us, algorithmic_bytes):
                 "valu_instructions_per_butterfly": e["valu_lane_instr_per_butterfly"],
                 "valu_peak": "36 T lane-ops/s measured (profiles/r01_microbench2_valu_issue_rates.txt)",
                 "hbm_frac_ceiling_at_this_instruction_count": algorithmic_bytes / (wi / peak) / 8e12,
-                "valu_source": "profiles/r04_pmc_lde_valu.json (rocprofv3 --pmc SQ_INSTS_VALU over the unit's launches)"}
+                "valu_source": "profiles/%s (rocprofv3 --pmc SQ_INSTS_VALU over the unit's launches)" % name,
+                "valu_profile_build": _stale_note(stale)}
     except Exception:
         return {"valu_frac": None, "valu_source": None}
+
+
+def proof_valu_view(key):
+    """VALU wave-instructions of ONE WHOLE proof of workload `key` (cfg2 | cfg2_keccak | cfg2_keccak_hiding | cfg3), counted by PMC over
+    every kernel the prover launches (profiles/r05_pmc_proofs.json, tools/r05_pmc_proofs.sh).  bench.py multiplies by the measured
+    proofs/s: the proof-level VALU issue fraction is the ruler that binds these workloads."""
+    name, pmc, stale = _profile_json(("r05_pmc_proofs.json",))
+    if pmc is None or key not in pmc.get("workloads", {}):
+        return None
+    w = pmc["workloads"][key]
+    return {"valu_wave_instr_per_proof": w["valu_wave_instr_per_proof"], "hash_kernels_share": w["hash_kernels_share"],
+            "peak_wave_instr_per_s": pmc["peak_wave_instr_per_s"], "top_kernels": [(k["kernel"], k["share"]) for k in w["kernels"][:4]],
+            "source": "profiles/%s, workload %s: rocprofv3 --pmc SQ_INSTS_VALU over every launch of one prover's proofs" % (name, key),
+            "profile_build": _stale_note(stale), "stale": stale}
 
 
 class _Worker(threading.Thread):
@@ -222,36 +258,21 @@ class FibAirJob:
         rate = 34 if self.hash == "keccak" else 8
         return sum(rows * ((w + rate - 1) // rate) + rows - 1 for rows, w in self.tree_shapes())
 
-    def _pmc_rows(self):
-        """Per-launch counter rows of the hash kernels of THIS hash configuration, from the committed PMC pass."""
-        import json
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        names = (("r03_pmc_keccak.json", "r02_pmc_keccak.json") if self.hash == "keccak"
-                 else ("r03_pmc_poseidon2.json", "r02_pmc_poseidon2.json"))
-        for name in names:
-            try:
-                with open(os.path.join(root, "profiles", name)) as f:
-                    pmc = json.load(f)
-            except Exception:
-                continue
-            if self.hash == "keccak":
-                rows = pmc["kernels"]
-                leaf = [r for r in rows if "keccak_leaf_kernel" in r["kernel"]]
-                comp = [r for r in rows if "keccak_compress_kernel" in r["kernel"]]
-            else:
-                leaf, comp = pmc.get("leaf_hash_f64", []), pmc.get("compress_layer_f64", [])
-            return name, leaf, comp
-        return None, [], []
+    def pmc_key(self):
+        """This job's workload in profiles/r05_pmc_proofs.json, or None (sizes the PMC pass did not cover)."""
+        return {("poseidon2", False, 20, 1): "cfg2", ("keccak", False, 20, 1): "cfg2_keccak", ("keccak", True, 20, 1): "cfg2_keccak_hiding",
+                ("poseidon2", False, 24, 2): "cfg3"}.get((self.hash, bool(self.hiding), self.log_height, self.log_blowup))
 
     def hash_roofline(self):
-        """The kernels that dominate a proof BY TIME are the leaf / compression layers of the hash that ran, and they are
-        VALU-bound, which the contract's hbm|mfma roofline cannot express.
-          achieved  = permutations / time of one commit of this job's trace tree as the prover runs it (HIP events);
-          frac      = VALU-busy of the launches that make up THIS tree (leaf layer of `rows` lanes, compression layers of rows/2,
-                      rows/4 ... lanes), weighted by their durations, from the committed PMC pass of the hash that ran
-                      (SQ_ACTIVE_INST_VALU / (256 CUs x GRBM_GUI_ACTIVE / 8), <= 1 by construction) — not a constant;
-          sustained_gperm_s = proofs/s x permutations per proof, filled in by bench.py from the timed region;
-          sustained_frac_of_kernel_ceiling = sustained / the rate of the bare permutation kernel measured in this run."""
+        """The ruler that binds a proof workload: VALU ISSUE over the whole proof.  A proof is a fixed number of VALU wave-instructions
+        (counted by PMC over every kernel one prover launches for it: profiles/r05_pmc_proofs.json, keyed by the build of libp3hip.so);
+        bench.py fills in
+          achieved = proofs/s of the timed region x that count   [G wave-instructions/s],   frac = achieved / 562.5 (measured issue peak).
+        Beside it, as context: which kernels the instructions belong to (the hash layers: 78-97 %), the hash kernels' own rate
+        (kernel_ceiling_gperm_s: one 2^24 x 2 commit timed in this run) and what the timed region sustained in permutations
+        (sustained_gperm_s, sustained_frac_of_kernel_ceiling: filled in by bench.py), and one commit of this job's trace tree ALONE
+        (`lone_tree`: a latency figure — a lone 2^21-leaf tree is seven launches down to 2^15 plus a latency-bound top; round 4 carried its
+        VALU-busy, 0.76, as `frac`, which described neither the four-prover run beside it nor the current kernels)."""
         n = self.tree_shapes()[0][0]  # rows of the trace tree (twice as many under hiding: the randomized trace has 2h rows)
         L = _lib.lib()
         kind = 1 if self.hash == "keccak" else 0
@@ -273,38 +294,22 @@ class FibAirJob:
         big_rows = 1 << 24  # a tree whose layers fill the chip for many workgroup generations: the kernels' own ceiling
         ms_big = commit_ms(big_rows, 4, best=True)
         hname = "Keccak-f[1600]" if kind else "Poseidon2-BabyBear-16"
-        out = {"bound": "valu", "hash": hname, "unit": "Gperm/s",
-               "kernel": "the hash layers as the prover runs them: one commit of 2^%d x 2 into pre-allocated layers (%s)" % (
-                   self.log_height + self.log_blowup,
-                   "keccak_leaf_kernel, keccak_compress_kernel, keccak_tree_levels[_coop]_kernel" if kind else
-                   "leaf_hash_f64_kernel, compress_layer_f64_kernel, tree_levels_coop_kernel"),
-               "achieved": perms / (ms * 1e-3) / 1e9, "permutations": perms, "avg_us": ms * 1e3,
-               "permutations_per_proof": self.permutations_per_proof()}
-        out["bare_permute_kernel_gperm_s"] = (self.keccak_rate() if kind else self.poseidon2_rate()) / 1e9
-        out["kernel_ceiling_gperm_s"] = (2 * big_rows - 1) / (ms_big * 1e-3) / 1e9
-        src, leaf, comp = self._pmc_rows()
-        if src is None:
-            out.update(frac=None, frac_source="no PMC pass committed for this hash configuration")
+        out = {"bound": "valu", "unit": "G wave-instr/s", "peak": 36e12 / 64 / 1e9, "achieved": None, "frac": None,
+               "peak_source": "36 T lane-ops/s measured (profiles/r01_microbench2_valu_issue_rates.txt)",
+               "hash": hname, "permutations_per_proof": self.permutations_per_proof(),
+               "kernel_ceiling_gperm_s": (2 * big_rows - 1) / (ms_big * 1e-3) / 1e9,
+               "bare_permute_kernel_gperm_s": (self.keccak_rate() if kind else self.poseidon2_rate()) / 1e9,
+               "lone_tree": {"what": "one commit of 2^%d x 2 into pre-allocated layers, nothing else on the chip (thread profile: %s)" % (
+                                 self.log_height + self.log_blowup, "latency"),
+                             "gperm_s": perms / (ms * 1e-3) / 1e9, "permutations": perms, "avg_us": ms * 1e3}}
+        key = self.pmc_key()
+        view = proof_valu_view(key) if key else None
+        if view is None:
+            out["valu_wave_instr_per_proof"] = None
+            out["source"] = "no PMC pass of whole proofs committed for this workload (profiles/r05_pmc_proofs.json covers cfg2, cfg2 under Keccak, Keccak + hiding, cfg3)"
             return out
-        # the launches of this tree: leaf layer of n lanes, compression layers of n/2, n/4, ... lanes (one state per lane)
-        want = [("leaf", n)] + [("compress", n >> k) for k in range(1, 30) if (n >> k) >= 1]
-        used, busy_t, dur_t = [], 0.0, 0.0
-        for what, lanes in want:
-            rows = leaf if what == "leaf" else comp
-            hit = [r for r in rows if r["grid_threads"] == lanes and "valu_busy_frac" in r]
-            if not hit:
-                continue
-            r = hit[-1]
-            busy_t += r["valu_busy_frac"] * r["duration_us"]
-            dur_t += r["duration_us"]
-            used.append({"layer": what, "lanes": lanes, "valu_busy": round(r["valu_busy_frac"], 4), "us": round(r["duration_us"], 1)})
-        big = [r for r in comp if r["grid_threads"] >= (1 << 20) and "valu_insts_per_wave" in r]
-        out["frac"] = busy_t / dur_t if dur_t else None
-        out["frac_source"] = ("profiles/%s: duration-weighted VALU-busy (SQ_ACTIVE_INST_VALU / (256 CUs x GRBM_GUI_ACTIVE / 8 XCDs)) over the "
-                              "per-lane launches of this job's 2^%d-leaf tree; the layers below the cooperative threshold (latency-bound, "
-                              "< 1 %% of the permutations) are not in it" % (src, self.log_height + self.log_blowup))
-        out["frac_layers"] = used
-        out["instructions_per_permutation"] = (sum(r["valu_insts_per_wave"] for r in big) / len(big)) if big else None
+        out.update({"valu_wave_instr_per_proof": view["valu_wave_instr_per_proof"], "hash_kernels_share": view["hash_kernels_share"],
+                    "top_kernels": view["top_kernels"], "source": view["source"], "profile_build": view["profile_build"]})
         return out
 
     def step_begin(self, instances=None, sink=None):

@@ -118,7 +118,7 @@ def test_other_workloads_condenses_child_lines_and_survives_a_failing_child(monk
             "config": {"workload": "fib_air 2^24-row trace"},
             "roofline": {"bound": "hbm", "achieved": 735.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.092, "traffic": 2.03e9, "avg_us": 912.0,
                          "algorithmic_bytes": 671088640, "kernel": "coset_lde_batch", "commit": {"gperm_s": 7.5}},
-            "valu_roofline": {"hash": "Poseidon2-BabyBear-16", "achieved": 8.5, "frac": 0.97, "sustained_gperm_s": 7.7}}
+            "valu_roofline": {"hash": "Poseidon2-BabyBear-16", "achieved": 545.6, "frac": 0.97, "sustained_gperm_s": 7.7, "valu_wave_instr_per_proof": 28.6e9}}
     calls = []
 
     def fake_run(cmd, **kw):
@@ -136,7 +136,7 @@ def test_other_workloads_condenses_child_lines_and_survives_a_failing_child(monk
     assert len(ok) == 3 and len(bad) == 1 and "boom" in bad[0]["error"] and "cfg5" in bad[0]["args"]
     e = ok[0]
     assert e["value"] == 19.1 and e["lde_frac"] == 0.092 and e["commit_gperm_s"] == 7.5 and e["lde_us"] == 912.0
-    assert e["hash_valu_busy"] == 0.97 and e["sustained_gperm_s"] == 7.7
+    assert e["proof_valu_issue_frac"] == 0.97 and e["sustained_gperm_s"] == 7.7 and e["valu_M_instr_per_proof"] == 28600.0
     assert len(json.dumps(res)) < 1900  # all four entries fit the last 2000 bytes of the line
     # a spent budget records the rest as skipped instead of starting children
     res = bench.other_workloads(budget_s=0.0)

@@ -442,7 +442,7 @@ def run(args, job, dist, world, rank, local_rank, n_dev, backend, coll_dev, use_
 
     # where a rank's wall time goes besides proving (seconds, timed region only): blocked in the scatter of the next step's
     # descriptors, blocked in retire() on the previous step's gather, blocked waiting for its own provers to finish a step
-    waits = {"scatter_wait_s": 0.0, "gather_wait_s": 0.0, "prover_join_s": 0.0}
+    waits = {"scatter_wait_s": 0.0, "gather_wait_s": 0.0, "prover_join_s": 0.0, "issue_host_s": 0.0, "gather_launch_s": 0.0}
     timing = {"on": False}
 
     def timed(key, fn):
@@ -478,7 +478,7 @@ def run(args, job, dist, world, rank, local_rank, n_dev, backend, coll_dev, use_
             width = torch.tensor([len(job.prove_one(0, 1))], dtype=torch.int64, device=coll_dev)
             dist.all_reduce(width, op=dist.ReduceOp.MAX)  # proofs of one parameter set have one length: the slot width
             coll_state["width"] = int(width.item())
-            coll_state["gatherer"] = pbatch.ProofGatherer(n_total, coll_dev)
+            coll_state["gatherer"] = pbatch.ProofGatherer(n_total, coll_dev, width=coll_state["width"])
             # every buffer of the run's one scatter exists before the timed region starts
             coll_state["scatterer"] = pbatch.DescriptorScatter(max(args.steps, args.warmup, 1), n_total, coll_dev)
         except Exception as e:
@@ -497,23 +497,24 @@ def run(args, job, dist, world, rank, local_rank, n_dev, backend, coll_dev, use_
             job.step_begin([(i, k * n_total + i) for i in pbatch.shard_instances(n_total, rank, world)])
             return None
         mine = descriptors(k)
-        rows = {i: r for r, (i, _, _) in enumerate(mine)}
-        put, slot = coll_state["gatherer"].open(len(mine), coll_state["width"])
-        if stub or os.environ.get("P3HIP_BENCH_DIRECT_SINK", "1") != "1":
-            job.step_begin([(i, a) for i, a, _ in mine], lambda i, pf: put(rows[i], i, pf))
-        else:
-            job.step_begin([(i, a) for i, a, _ in mine], _DirectSink(put, rows))
-        return slot
+
+        def begin():
+            rows = {i: r for r, (i, _, _) in enumerate(mine)}
+            put, slot = coll_state["gatherer"].open(len(mine), coll_state["width"])
+            if stub or os.environ.get("P3HIP_BENCH_DIRECT_SINK", "1") != "1":
+                job.step_begin([(i, a) for i, a, _ in mine], lambda i, pf: put(rows[i], i, pf))
+            else:
+                job.step_begin([(i, a) for i, a, _ in mine], _DirectSink(put, rows))
+            return slot
+        return timed("issue_host_s", begin)
 
     def retire(slot):
         got = timed("prover_join_s", job.step_end)
         if slot is None:
             return got
 
-        def gather():
-            prev, coll_state["pending"] = coll_state.get("pending"), coll_state["gatherer"].launch(slot)
-            return prev.wait(copy=False) if prev is not None else None
-        return timed("gather_wait_s", gather)
+        prev, coll_state["pending"] = coll_state.get("pending"), timed("gather_launch_s", lambda: coll_state["gatherer"].launch(slot))
+        return timed("gather_wait_s", lambda: prev.wait(copy=False) if prev is not None else None)
 
     def run_steps(first, count):
         # A failed collective is FATAL: an N-GPU line must never be printed without RCCL having moved the batch.
@@ -538,6 +539,13 @@ def run(args, job, dist, world, rank, local_rank, n_dev, backend, coll_dev, use_
             os._exit(3)
 
     run_steps(0, args.warmup)
+    # The issuing thread must not stop for the interpreter's cyclic garbage collector inside the timed region: with torch imported a
+    # full collection walks ~10^6 objects (tens of milliseconds), and the multi-rank path allocates enough small objects per step
+    # (descriptor tuples, views of the gathered rows) to trigger one where the single-rank path does not — it showed as ~35 ms of a
+    # 2.2 s run that no timer of the loop owned.  Collect now, then keep the collector off until the run is over.
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
     timing["on"] = True
     t0 = time.perf_counter()
@@ -546,13 +554,14 @@ def run(args, job, dist, world, rank, local_rank, n_dev, backend, coll_dev, use_
     barrier()
     elapsed = time.perf_counter() - t0
     timing["on"] = False
+    gc.enable()
     cur_dev = -1 if stub else torch.cuda.current_device()
     # one row per rank, so that an N-rank line explains itself: what the rank proved, how long its own steps took, where it waited
     # (a scaling loss shows up as one rank's prove_wall_s, or as gather / scatter waits), and which host cores it ran on
     int_keys = ("rank", "local_rank", "device_count", "device", "proofs", "host_cores", "pinned")
-    flt_keys = ("prove_wall_s", "scatter_wait_s", "gather_wait_s", "prover_join_s")
+    flt_keys = ("prove_wall_s", "scatter_wait_s", "gather_wait_s", "prover_join_s", "issue_host_s", "gather_launch_s")
     mine = [rank, local_rank, n_dev, cur_dev, args.batch * args.steps, len(HOST_CORES), 1 if PINNING.startswith("pinned") else 0,
-            own_wall, waits["scatter_wait_s"], waits["gather_wait_s"], waits["prover_join_s"]]
+            own_wall, waits["scatter_wait_s"], waits["gather_wait_s"], waits["prover_join_s"], waits["issue_host_s"], waits["gather_launch_s"]]
 
     def rank_row(vals):
         d = {k: int(v) for k, v in zip(int_keys, vals)}
@@ -601,7 +610,8 @@ def run(args, job, dist, world, rank, local_rank, n_dev, backend, coll_dev, use_
         "dist_backend": (backend + (" (= RCCL on ROCm)" if backend == "nccl" else "")) if use_dist else None,
         "ranks": ranks_info,
         "ranks_note": "per rank: proofs and prove_wall_s of its own timed steps (before the closing barrier), seconds blocked in the "
-                      "descriptor scatter / in retire() on the proof gather / joining its own provers, host cores in its affinity mask; "
+                      "descriptor scatter / in retire() on the previous step's proof gather / joining its own provers, host time spent opening a staging slot and dealing a "
+                      "step to the provers (issue_host_s) and enqueuing a step's gather (gather_launch_s), host cores in its affinity mask; "
                       "host_core_list and pinning are rank 0's (every rank applies the same rule to its own GPU)",
         "gather_bytes_per_step": (n_total * coll_state["width"]) if use_gather and "width" in coll_state else 0,
         "descriptor_scatters_in_timed_region": (1 if args.steps > 0 else 0) if use_gather else 0,

@@ -237,12 +237,19 @@ class ProofGatherer:
     a step is one collective.  `width` must be the same on every rank: proofs of one parameter set have one length, so
     the caller learns it from the first step (gather_proofs_async does the all_reduce) and passes it from then on."""
 
-    def __init__(self, n_total, device="cpu"):
+    def __init__(self, n_total, device="cpu", width=None):
         self.n_total, self.device = n_total, str(device)
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.per = (n_total + self.world - 1) // self.world
         self.slots, self.turn = {}, 0
         self.stream = collective_stream(device)
+        if width is not None:
+            # all three staging slots now (pinned host rows, device rows, receive and landing buffers): a slot created on first use
+            # page-locks tens of megabytes, which must not happen inside a timed region (round 5: the third slot was first used by the
+            # first TIMED step after two warmup steps: ~90 ms of a 1.7 s run)
+            for _ in range(3):
+                self._slot(width)
+            self.turn = 0
 
     def _slot(self, width):
         self.turn = (self.turn + 1) % 3
@@ -254,6 +261,8 @@ class ProofGatherer:
             h = torch.zeros((self.per, row), dtype=torch.uint8)
             ent = {"h": h.pin_memory() if gpu else h, "width": width}
             if gpu:
+                ent["event"] = torch.cuda.Event()  # one per slot, re-recorded by every launch (creating / destroying an event per step
+                                                   # costs the issuing thread ~1 ms a step under load: hipEventDestroy)
                 ent["d"] = torch.empty((self.per, row), dtype=torch.uint8, device=self.device)
                 if self.rank == 0:
                     ent["rb"] = [torch.empty_like(ent["d"]) for _ in range(self.world)]
@@ -298,7 +307,7 @@ class ProofGatherer:
                 for src, dst in zip(bufs, ent["lb"]):
                     dst.copy_(src, non_blocking=True)
                 rows = ent["lb"]
-            event = torch.cuda.Event()
+            event = ent["event"]
             event.record(self.stream)
         return _PendingGather(work, rows, self.n_total, ent, event)
 

@@ -207,19 +207,12 @@ class FibAirJob:
         import json
         roof = self.lde_roofline(reps=20)
         traffic, src = None, None
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        for name in ("r04_pmc_lde.json", "r03_pmc_lde.json", "r02_pmc_lde.json", "r01_pmc_lde_v2.json"):
-            try:
-                with open(os.path.join(root, "profiles", name)) as f:
-                    pmc = json.load(f)
-                key = {(20, 1): "cfg2_lde_2^20x2_blowup2", (24, 2): "cfg3_lde_2^24x2_blowup4"}.get((self.log_height, self.log_blowup))
-                if key and key in pmc:
-                    traffic = pmc[key]["total_bytes"]
-                    src = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, summed over "
-                           "the unit's launches (tools/pmc_probe.py, tools/pmc_summarize.py)" % name)
-                    break
-            except Exception:
-                continue
+        name, pmc, stale = _profile_json(("r05_pmc_lde.json", "r04_pmc_lde.json", "r03_pmc_lde.json", "r02_pmc_lde.json", "r01_pmc_lde_v2.json"))
+        key = {(20, 1): "cfg2_lde_2^20x2_blowup2", (24, 2): "cfg3_lde_2^24x2_blowup4"}.get((self.log_height, self.log_blowup))
+        if pmc is not None and key and key in pmc:
+            traffic = pmc[key]["total_bytes"]
+            src = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, summed over "
+                   "the unit's launches (tools/pmc_probe.py, tools/pmc_summarize.py); %s" % (name, _stale_note(stale)))
         out = {"bound": "hbm", "achieved": roof["gbps"], "peak": 8000.0, "unit": "GB/s", "frac": roof["gbps"] / 8000.0,
                "frac_of_achievable_6300": roof["gbps"] / 6300.0, "traffic": traffic, "traffic_source": src,
                "kernel": "coset_lde_batch (narrow plan: one unit of " + str(roof.get("launches", "3")) + " launches)",
@@ -524,11 +517,7 @@ class WideCommitJob:
         perms = H * ((self.width + 7) // 8) + H - 1 if self.hash == "poseidon2" else H * ((((self.width + 1) // 2) + 16) // 17) + H - 1
         traffic, src = None, None
         try:
-            import json
-            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-            name = "r04_pmc_lde.json" if os.path.exists(os.path.join(root, "profiles", "r04_pmc_lde.json")) else "r03_pmc_lde.json"
-            with open(os.path.join(root, "profiles", name)) as f:
-                pmc = json.load(f)
+            name, pmc, stale = _profile_json(("r05_pmc_lde.json", "r04_pmc_lde.json", "r03_pmc_lde.json"))
             if (self.log_height, self.width, self.log_blowup) == (16, 2633, 1) and "cfg5_lde_2^16x2633_blowup2" in pmc:
                 traffic = pmc["cfg5_lde_2^16x2633_blowup2"]["total_bytes"]
                 src = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE, separate passes, summed over the unit's launches "
@@ -536,7 +525,7 @@ class WideCommitJob:
                        "K3's access shape (4-byte lanes on 128-byte segments of 10532-byte rows) shows those reads tallied in full "
                        "(profiles/r04_fetch_calib.json: factor 1.016 against 2.000 for the same access on 128-byte-multiple rows), so round 3's "
                        "2.73 GB for K3's 1.38 GB input was the correction, not a double fetch.  The structure moves 6.2 GB = 9 matrix sweeps; what "
-                       "is above that is write amplification on rows that are not multiples of 128 bytes" % name)
+                       "is above that is write amplification on rows that are not multiples of 128 bytes; %s" % (name, _stale_note(stale)))
         except Exception:
             pass
         return {"bound": "hbm", "kernel": "coset_lde_batch of the wide matrix (two-digit plan with 128-byte tile rows: narrow_inv1 / narrow_mid / narrow_fwd2 <8, 5, 1>)",

@@ -79,5 +79,9 @@ if marks:
     tail = [l for l in launches[marks[-1] + 1:] if "ntt_" in l["kernel"] or "narrow" in l["kernel"] or "bit_reverse" in l["kernel"]]
     out["cfg5_lde_2^16x2633_blowup2"] = {"launches": tail, "total_bytes": sum(l["fetch_bytes"] + l["write_bytes"] for l in tail),
                                          "algorithmic_bytes": 4 * (1 << 16) * 2633 * 3}
+import hashlib  # noqa: E402
+import os  # noqa: E402
+_lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "plonky3-mobile_amd", "libp3hip.so")
+out["lib_sha256"] = hashlib.sha256(open(_lib, "rb").read()).hexdigest()  # the build these counts belong to (bench_support._profile_json)
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps({k: (v["total_bytes"], v["algorithmic_bytes"]) for k, v in out.items() if k.startswith("cfg")}))

@@ -26,6 +26,7 @@
 #include "poseidon2_f64.hip.h"
 #include "prover.h"
 #include "rng.h"
+#include "rng_dev.hip.h"
 #include "transcript.hip.h"
 
 namespace p3 {

@@ -19,4 +19,7 @@ bool rng_fill_supported(uint64_t n);
 // would leave it; *err |= 1 if the fill ran out of raw draws (does not happen with the margin used)
 int rng_fill_field(Context& cx, hipStream_t stream, DevRng* st, uint32_t* out, uint64_t n, uint32_t* workspace, uint32_t* err);
 
+// the context's device copy of the generator's GF(2) jump matrices (J_k = T^(256 * 2^k), lane-interleaved basis), uploaded at first use
+int rng_jump_table(Context& cx, const uint64_t** out);
+
 }  // namespace p3

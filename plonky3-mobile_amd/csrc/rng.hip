@@ -22,15 +22,13 @@
 #include "bb31.hip.h"
 #include "common.h"
 #include "rng.h"
+#include "rng_dev.hip.h"
 
 #include <algorithm>
 #include <memory>
 #include <mutex>
 
 namespace p3 {
-
-constexpr uint32_t RNG_CHUNK_LOG = 8, RNG_CHUNK = 1u << RNG_CHUNK_LOG;  // raw draws per lane
-constexpr uint32_t RNG_MAX_JUMP = 22;                                    // up to 2^22 chunks per fill
 
 // ---- host: SplitMix64 seeding and the GF(2) jump matrices ----
 void rng_seed_from_u64(uint64_t s[4], uint64_t state) {
@@ -42,19 +40,6 @@ void rng_seed_from_u64(uint64_t s[4], uint64_t state) {
         s[i] = z ^ (z >> 31);
     }
 }
-__host__ __device__ __forceinline__ uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
-__host__ __device__ __forceinline__ uint64_t xoshiro_next(uint64_t (&s)[4]) {
-    const uint64_t result = rotl64(s[0] + s[3], 23) + s[0];
-    const uint64_t t = s[1] << 17;
-    s[2] ^= s[0];
-    s[3] ^= s[1];
-    s[1] ^= s[2];
-    s[0] ^= s[3];
-    s[2] ^= t;
-    s[3] = rotl64(s[3], 45);
-    return result;
-}
-
 namespace {
 struct Bits256 { uint64_t w[4]; };
 struct Mat256 { Bits256 col[256]; };  // M v = xor of col[j] over the set bits j of v
@@ -102,63 +87,6 @@ const std::vector<uint64_t>& jump_matrices() {
 }
 }  // namespace
 
-// ---- device ----
-// GF(2) matrix-vector product by ONE WAVE in the lane-interleaved basis (see jump_matrices): the state is wave-uniform
-// (four 64-bit words in SGPRs), lane l holds the four rows that produce its bits, an output bit is the parity of
-// row & state, and the new state words are the four BALLOTS of those bits — no shuffle, no LDS, ~80 instructions.
-struct LaneRows { uint64_t r[4][4]; };
-__device__ __forceinline__ LaneRows load_rows(const uint64_t* __restrict__ m) {
-    LaneRows k;
-    const uint32_t lane = threadIdx.x & 63u;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const ulonglong2* p = reinterpret_cast<const ulonglong2*>(m + ((size_t)i * 64 + lane) * 4);
-        const ulonglong2 a = p[0], b = p[1];
-        k.r[i][0] = a.x; k.r[i][1] = a.y; k.r[i][2] = b.x; k.r[i][3] = b.y;
-    }
-    return k;
-}
-__device__ __forceinline__ void wave_matvec(const LaneRows& k, uint64_t (&s)[4]) {
-    uint64_t out[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint64_t x = (k.r[i][0] & s[0]) ^ (k.r[i][1] & s[1]) ^ (k.r[i][2] & s[2]) ^ (k.r[i][3] & s[3]);
-        const uint32_t f = (uint32_t)x ^ (uint32_t)(x >> 32);
-        out[i] = __ballot((__builtin_popcount(f) & 1) != 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) s[i] = out[i];
-}
-// original basis -> lane-interleaved basis of a wave-uniform state: word i, bit l = original bit 4l + i
-__device__ __forceinline__ void to_interleaved(uint64_t (&s)[4]) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t word = lane < 32u ? (lane < 16u ? s[0] : s[1]) : (lane < 48u ? s[2] : s[3]);
-    const uint32_t bit0 = (lane & 15u) * 4u;
-    uint64_t out[4];
-#pragma unroll
-    for (uint32_t i = 0; i < 4; i++) out[i] = __ballot(((word >> (bit0 + i)) & 1ull) != 0);
-#pragma unroll
-    for (int i = 0; i < 4; i++) s[i] = out[i];
-}
-// lane-interleaved -> original basis, per lane (each lane its own state): original word W = bits 4l + i of the
-// interleaved words for l = 16W .. 16W + 15, i.e. a 4-way bit interleave of four 16-bit pieces
-__device__ __forceinline__ uint64_t spread16(uint64_t x) {  // bit k of x (k < 16) -> bit 4k
-    x &= 0xffffull;
-    x = (x | (x << 24)) & 0x000000ff000000ffull;
-    x = (x | (x << 12)) & 0x000f000f000f000full;
-    x = (x | (x << 6)) & 0x0303030303030303ull;
-    x = (x | (x << 3)) & 0x1111111111111111ull;
-    return x;
-}
-__device__ __forceinline__ void from_interleaved(uint64_t (&s)[4]) {
-    uint64_t out[4];
-#pragma unroll
-    for (int w = 0; w < 4; w++)
-        out[w] = spread16(s[0] >> (16 * w)) | (spread16(s[1] >> (16 * w)) << 1) | (spread16(s[2] >> (16 * w)) << 2) |
-                 (spread16(s[3] >> (16 * w)) << 3);
-#pragma unroll
-    for (int w = 0; w < 4; w++) s[w] = out[w];
-}
 // exclusive scan of counts[0..n) in two levels: every workgroup scans its 1024 counts in place and leaves their total in
 // bsum[block]; one workgroup then scans the block totals; pass 2 adds bsum[chunk / 1024] to the in-block offset.
 // (One workgroup walking the whole array took 183 us for the 2^17.8 chunks of the prover's largest fill.)
@@ -319,57 +247,16 @@ __global__ void __launch_bounds__(256) rng_compact_kernel(DevRng* st, const uint
 // walking 63 jump products each for chunks nobody needs, two scan launches over a few counters).  Lane l walks to chunk l (only the
 // chunks the fill can need), generates its 256 candidates into LDS, the wave scans the 32 counts in registers and compacts chunk by
 // chunk with ballot ranks; the lane that owns the chunk of the n-th element replays it and leaves the generator state.
-constexpr uint32_t RNG_SMALL_CHUNKS = 32, RNG_SMALL_STRIDE = RNG_CHUNK + 1;
 __global__ void __launch_bounds__(64) rng_small_fill_kernel(DevRng* st, const uint64_t* __restrict__ jump, uint32_t n_chunks, uint32_t* out, uint32_t n,
                                                             uint32_t* err) {
     __shared__ uint32_t raw[RNG_SMALL_CHUNKS * RNG_SMALL_STRIDE];
     const uint32_t lane = threadIdx.x;
-    uint64_t cur[4] = {st->s[0], st->s[1], st->s[2], st->s[3]};
-    to_interleaved(cur);
-    const LaneRows j0 = load_rows(jump);
-    uint64_t s[4] = {cur[0], cur[1], cur[2], cur[3]};
-    for (uint32_t i = 1; i < n_chunks; i++) {
-        wave_matvec(j0, cur);
-        if (lane == i) { s[0] = cur[0]; s[1] = cur[1]; s[2] = cur[2]; s[3] = cur[3]; }
-    }
-    from_interleaved(s);
-    const uint64_t s_start[4] = {s[0], s[1], s[2], s[3]};
-    uint32_t cnt = 0;
-    if (lane < n_chunks) {
-        for (uint32_t i = 0; i < RNG_CHUNK; i++) {
-            const uint32_t v = (uint32_t)(xoshiro_next(s) >> 32) >> 1;
-            cnt += v < bb::P ? 1u : 0u;
-            raw[lane * RNG_SMALL_STRIDE + i] = v;
-        }
-    }
-    uint32_t inc = cnt;  // inclusive scan of the chunk counts over the wave
-#pragma unroll
-    for (uint32_t off = 1; off < 64; off <<= 1) {
-        const uint32_t u = (uint32_t)__shfl_up((int)inc, off, 64);
-        if (lane >= off) inc += u;
-    }
-    const uint32_t my_base = inc - cnt;
-    __syncthreads();  // one wave: orders the LDS writes before the reads below
-    for (uint32_t c = 0; c < n_chunks; c++) {  // wave-uniform
-        const uint32_t base = (uint32_t)__shfl((int)my_base, (int)c, 64);
-        if (base >= n) break;
-        uint32_t v[4], below = 0;
-        bool acc[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            v[k] = raw[c * RNG_SMALL_STRIDE + 4 * lane + k];
-            acc[k] = v[k] < bb::P;
-            const uint64_t b = __ballot(acc[k]);
-            below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, below));
-        }
-        uint32_t rank = base + below;
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (acc[k]) { if (rank < n) out[rank] = v[k]; rank++; }
-    }
-    // generator state right after the n-th accepted draw: the lane whose chunk holds it replays that chunk
-    const uint32_t total = (uint32_t)__shfl((int)inc, 63, 64);
+    const uint64_t seed[4] = {st->s[0], st->s[1], st->s[2], st->s[3]};
+    uint64_t s_start[4];
+    uint32_t my_base, cnt;
+    const uint32_t total = rng_small_fill_wave(seed, jump, n_chunks, raw, out, n, s_start, my_base, cnt);  // rng_dev.hip.h
     if (total < n) { if (lane == 0) atomicOr(err, 1u); return; }  // ran out of raw draws (never, with the margin used)
+    // generator state right after the n-th accepted draw: the lane whose chunk holds it replays that chunk
     if (lane < n_chunks && my_base < n && n <= my_base + cnt) {
         uint64_t r[4] = {s_start[0], s_start[1], s_start[2], s_start[3]};
         uint32_t need = n - my_base;  // accepted draws of this chunk up to and including the n-th element
@@ -409,21 +296,26 @@ int rng_workspace_words(uint64_t n_max, size_t* words) {
     return OK;
 }
 
-int rng_fill_field(Context& cx, hipStream_t stream, DevRng* st, uint32_t* out, uint64_t n, uint32_t* workspace, uint32_t* err) {
-    if (!n) return OK;
-    // jump matrices: one copy per (thread, device) context
+// jump matrices: one copy per (thread, device) context, uploaded at first use
+int rng_jump_table(Context& cx, const uint64_t** out) {
     if (!cx.rng_jump) {
         const std::vector<uint64_t>& j = jump_matrices();
         P3_HIP(hipMalloc(reinterpret_cast<void**>(&cx.rng_jump), j.size() * 8));
         P3_HIP(hipMemcpy(cx.rng_jump, j.data(), j.size() * 8, hipMemcpyHostToDevice));
     }
+    if (out) *out = cx.rng_jump;
+    return OK;
+}
+
+int rng_fill_field(Context& cx, hipStream_t stream, DevRng* st, uint32_t* out, uint64_t n, uint32_t* workspace, uint32_t* err) {
+    if (!n) return OK;
+    { int rc = rng_jump_table(cx, nullptr); if (rc) return rc; }
     // raw draws: n / (P / 2^31) = n * 1.0667 expected; 12.5 % + 64 chunks of margin is > 50 standard deviations
     {   // small fills: one launch (rng_small_fill_kernel).  Margin: n / 8 + 1024 raw draws beyond n is > 50 standard deviations of the
         // rejections for every n (expected n / 15, deviation 0.27 sqrt(n))
-        const uint64_t raw_small = n + n / 8 + 1024;
-        const uint64_t chunks_small = (raw_small + RNG_CHUNK - 1) / RNG_CHUNK;
-        if (chunks_small <= RNG_SMALL_CHUNKS) {
-            hipLaunchKernelGGL(rng_small_fill_kernel, dim3(1), dim3(64), 0, stream, st, cx.rng_jump, (uint32_t)chunks_small, out, (uint32_t)n, err);
+        const uint32_t chunks_small = rng_small_chunks(n);
+        if (chunks_small) {
+            hipLaunchKernelGGL(rng_small_fill_kernel, dim3(1), dim3(64), 0, stream, st, cx.rng_jump, chunks_small, out, (uint32_t)n, err);
             P3_HIP(hipGetLastError());
             return OK;
         }

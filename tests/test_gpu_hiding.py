@@ -163,6 +163,38 @@ def test_hiding_bench_size_proof_bytes_equal_oracle_slow(p3, oracle):
         pytest.fail("proof words differ first at %d of %d" % (int(np.nonzero(w1 != w2)[0][0]), len(w1)))
 
 
+@pytest.mark.parametrize("hash", ["poseidon2", "keccak"])
+def test_one_launch_prover_of_tiny_instances(p3, oracle, hash):
+    """prover_tiny.hip.inc: under the latency profile a hiding proof whose LDE domain has at most 2^8 points (and whose random
+    streams fit one wave's small fill, proof-of-work <= 4 bits) is ONE kernel launch of one workgroup — the reference's own
+    instance (n = 8, x = 21, create_test_fri_params(_, 2): log_n 3, FRI (2, 2, 2, 1), fib_air.rs:56-72) and log_n 1..6 around it.
+    Bytes equal the oracle prover's for both hashes, twice per prover (arena reuse), for several first rows and seeds; the
+    throughput profile (the multi-launch sequence) gives the same bytes; sizes past the bound fall back to the general path."""
+    kind = oracle.HASH_KECCAK if hash == "keccak" else oracle.HASH_POSEIDON2
+    # (log_final_poly_len must stay below log_n + 1: 1 for log_n = 1); log_n 6 at blowup 4 = 2^9 points: general path
+    cases = [(log_n, (2, 2 if log_n > 1 else 1, 2, 1)) for log_n in range(1, 7)]
+    cases += [(1, (1, 0, 4, 2)), (2, (1, 1, 3, 0)), (4, (1, 0, 6, 3)), (5, (2, 1, 5, 4)), (6, (1, 3, 9, 2)), (4, (3, 0, 2, 1)), (3, (4, 2, 3, 0))]
+    for log_n, t in cases:
+        gfp, ofp = _fp(p3, oracle, *t)
+        for seed in (1, 77):
+            provers = [p3.FibAirProver(log_n, params=gfp, hash=hash, hiding=True, seed=seed, profile=pf) for pf in ("latency", "throughput")]
+            for a, b in [(0, 1), (5, 9)]:
+                ref = oracle.prove_fib_air_hiding(a, b, log_n, ofp, hash=kind, seed=seed)
+                for pr in provers:
+                    proof = pr.prove(a, b)
+                    assert len(proof) == len(ref), (log_n, t, seed, pr.profile)
+                    if proof != ref:
+                        w1, w2 = np.frombuffer(proof, np.uint32), np.frombuffer(ref, np.uint32)
+                        pytest.fail("log_n %d, fri %r, seed %d, %s profile: proof words differ first at %d of %d" % (
+                            log_n, t, seed, pr.profile, int(np.nonzero(w1 != w2)[0][0]), len(w1)))
+                x = oracle.fib_public_x(a, b, 1 << log_n)
+                assert oracle.verify_fib_air_hiding(ref, a, b, x, log_n, ofp, hash=kind) == 0
+            for pr in provers:
+                pr.close()
+    # the reference's report entry point proves exactly this instance (Keccak, hiding, seed 1) through the latency profile
+    assert p3.run_fib_air_zk_report().startswith("fib_air zk ok (n=8, x=21)")
+
+
 def test_hiding_prover_at_its_largest_domain(p3, oracle):
     """The hiding prover admits LDE domains up to 2^24 points (log_n + 1 + log_blowup <= 24; prover.h MAX_LOG_DOMAIN_HIDING).  At
     the bound — 2^22-row trace, randomized to 2^23, blowup 2, Keccak hashes — the oracle's verifier accepts the proof and rejects

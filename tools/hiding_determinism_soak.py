@@ -2,7 +2,8 @@
 """The hiding prover's side streams under load: N prover threads prove the SAME few instances over and over at two sizes; every proof
 of an instance must have the same bytes as the first one (the streams restart from the seed for every proof), and the host verifier
 must accept.  A missed cross-stream dependency (fills / randomization commitment racing their consumers) would show up as a differing
-or rejected proof.   python3 tools/r04_hiding_determinism_soak.py [threads=4] [rounds=6]   (also run with P3HIP_HIDING_R_SIDE=1)"""
+or rejected proof.   python3 tools/hiding_determinism_soak.py [threads=4] [rounds=6]   [profile=throughput|latency]
+(the latency profile commits the randomization polynomial on a second side stream: round 4's P3HIP_HIDING_R_SIDE=1)"""
 import os
 import sys
 import threading
@@ -15,6 +16,7 @@ from __graft_entry__ import load_package  # noqa: E402
 p3 = load_package()
 threads = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+profile = sys.argv[3] if len(sys.argv) > 3 else "throughput"
 bad = []
 for log_n, reps in ((14, 6 * rounds), (19, rounds)):
     fp = p3.FriParameters(1, 0, 20, 8)
@@ -24,7 +26,7 @@ for log_n, reps in ((14, 6 * rounds), (19, rounds)):
 
     def worker(k):
         torch.cuda.set_device(0)
-        pr = p3.FibAirProver(log_n, params=fp, hash="keccak", hiding=True, seed=1)
+        pr = p3.FibAirProver(log_n, params=fp, hash="keccak", hiding=True, seed=1, profile=profile)
         for r in range(reps):
             a, b = insts[(r + k) % len(insts)]
             pf = pr.prove(a, b)

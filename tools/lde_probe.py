@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A few coset LDEs (bit-reversed output) of given shapes, for rocprofv3 kernel traces / PMC passes of the narrow plan:
-   [P3HIP_NTT_NARROW_F64=0|7] rocprofv3 --kernel-trace --stats ... -- python3 tools/lde_probe.py 20:2:1 22:4:2 [reps]
+   rocprofv3 --kernel-trace --stats ... -- python3 tools/lde_probe.py 20:2:1 22:4:2 [reps]
 shape = log_height:width:log_blowup."""
 import ctypes as C
 import os

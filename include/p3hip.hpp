@@ -158,9 +158,12 @@ struct FriParameters {  // p3_fri::FriParameters; defaults = create_benchmark_fr
 class FibAirProver {  // prove(&config, &FibonacciAir{}, generate_trace_rows(a, b, n), &pis), fib_air.rs:61-70
   public:
     // hash: P3HIP_HASH_POSEIDON2 (north_star) or P3HIP_HASH_KECCAK (the reference's own hashes, fib_air.rs:28-53)
-    FibAirProver(unsigned log_n, FriParameters fp = FriParameters(), int hash = P3HIP_HASH_POSEIDON2) {
+    // profile (include/p3hip.h PROFILES): fixed at creation, like the reference's backend (native/src/gpu_dft.rs:85-92).  A prover made on its
+    // own proves one proof at a time: the latency profile; provers that share the chip take P3HIP_PROFILE_THROUGHPUT.
+    FibAirProver(unsigned log_n, FriParameters fp = FriParameters(), int hash = P3HIP_HASH_POSEIDON2, int profile = P3HIP_PROFILE_LATENCY,
+                 bool hiding = false, uint64_t seed = 1) {
         p3hip_fri_params_t c{fp.log_blowup, fp.log_final_poly_len, fp.num_queries, fp.proof_of_work_bits};
-        check(p3hip_fib_prover_create_hash(hash, log_n, &c, nullptr, 1, &h_));
+        check(p3hip_fib_prover_create_profile(profile, hash, hiding ? 1 : 0, hiding ? seed : 0, log_n, &c, nullptr, 1, &h_));
     }
     FibAirProver(const FibAirProver&) = delete;
     ~FibAirProver() { if (h_) p3hip_fib_prover_destroy(h_); }

@@ -45,4 +45,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_hid -o hid -- 
 cd $ROOT
 say "2 ranks started by bench.py --gpus 2 over gloo on one GPU (NOT RCCL): a rehearsal of the launcher and the collectives"
 P3HIP_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --workload cfg4 --steps 5 --warmup 1 2> $OUT/bench_2rank_gloo.err | grep '^{' > $OUT/bench_cfg4_2rank_gloo_rehearsal.json
+say "single-proof latency under the two creation-time profiles (no environment variable)"
+bash tools/r05_latency_profiles.sh > $OUT/latency.log 2>&1; cp gpurun_out/r05_latency_profiles.txt $OUT/latency_profiles.txt
+say "the one-launch prover: phase stamps of a diagnostic build (tools/r05_tiny_stamps.sh built it into tools/_bin before the run)"
+if [ -f tools/_bin/libp3hip_stamps.so ]; then
+  P3HIP_LIB=$ROOT/tools/_bin/libp3hip_stamps.so python3 tools/single_proof_latency.py 3 keccak 1 4 latency > $OUT/tiny_stamps_keccak.txt 2>&1
+  P3HIP_LIB=$ROOT/tools/_bin/libp3hip_stamps.so python3 tools/single_proof_latency.py 3 poseidon2 1 4 latency > $OUT/tiny_stamps_poseidon2.txt 2>&1
+fi
 say done

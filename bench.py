@@ -70,7 +70,7 @@ def cpu_baseline_fib(log_height, job, hash_kind=0, hiding=False):
            "seconds": dt, "proof_bytes": len(proof), "build_flags": o.build_flags(),
            "all_cores": {"value": 1.0 / dt_mt, "unit": "proofs/s", "cores": cores, "seconds": dt_mt,
                          "same_bytes": bool(proof_mt == proof),
-                         "note": "same C port, OpenMP over the hashing/opening/folding loops; transforms and transcript serial"}}
+                         "note": "same C port, OpenMP over the hashing/opening/folding loops; transforms threaded over blocks of rows / the butterflies of a stage since round 5 (oracle/dft.c); the transcript, the proof-of-work search and (hiding) the random draws are serial"}}
     if sample_log == log_height:
         gpu = job.prove_one(0, 1)
         out["proof_bytes_equal_to_gpu"] = bool(gpu == proof)

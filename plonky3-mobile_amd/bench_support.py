@@ -289,6 +289,10 @@ class FibAirJob:
         hname = "Keccak-f[1600]" if kind else "Poseidon2-BabyBear-16"
         out = {"bound": "valu", "unit": "G wave-instr/s", "peak": 36e12 / 64 / 1e9, "achieved": None, "frac": None,
                "peak_source": "36 T lane-ops/s measured (profiles/r01_microbench2_valu_issue_rates.txt)",
+               "peak_note": "562.5 G wave-instructions/s is the measured issue rate of the 4-cycle VALU classes (32-bit multiplies, v_mad_u64_u32, fp64, "
+                            "v_min / v_add3 / shifts: 512-566 G/s at >= 2 waves per SIMD in that microbenchmark); v_add / v_sub / v_and-class "
+                            "instructions issue in ~3 cycles (830-870 G/s), so a proof whose mix is mostly 32-bit logic (Keccak without hiding) can read "
+                            "above 1.0 on this ruler; the Poseidon2 (fp64) and hiding workloads cannot",
                "hash": hname, "permutations_per_proof": self.permutations_per_proof(),
                "kernel_ceiling_gperm_s": (2 * big_rows - 1) / (ms_big * 1e-3) / 1e9,
                "bare_permute_kernel_gperm_s": (self.keccak_rate() if kind else self.poseidon2_rate()) / 1e9,

@@ -65,13 +65,12 @@ const std::vector<uint64_t>& jump_matrices() {
             (void)xoshiro_next(s);
             for (int k = 0; k < 4; k++) a->col[j].w[k] = s[k];
         }
-        for (uint32_t i = 0; i < RNG_CHUNK_LOG; i++) { matsquare(*a, b.get()); a.swap(b); }
         // Stored ROW-major in the lane-interleaved basis the device works in: permuted index p = 64 i + l stands for
         // state bit 4 l + i (lane l of a wave owns bits 4l .. 4l+3), so that the four ballots of a wave ARE the four
         // words of the product.  Row p_out = mask over permuted input indices; rows 64 i + l, i = 0..3, belong to lane l.
         auto orig = [](int p) { return 4 * (p & 63) + (p >> 6); };
-        flat.resize((size_t)RNG_MAX_JUMP * 256 * 4);
-        for (uint32_t k = 0; k < RNG_MAX_JUMP; k++) {
+        flat.resize((size_t)(RNG_MAX_JUMP + 1) * 256 * 4);
+        auto store = [&](uint32_t k) {
             for (int po = 0; po < 256; po++) {
                 uint64_t row[4] = {0, 0, 0, 0};
                 const int bo = orig(po);
@@ -79,6 +78,14 @@ const std::vector<uint64_t>& jump_matrices() {
                     if ((a->col[orig(pi)].w[bo >> 6] >> (bo & 63)) & 1) row[pi >> 6] |= 1ull << (pi & 63);
                 for (int w = 0; w < 4; w++) flat[((size_t)k * 256 + po) * 4 + w] = row[w];
             }
+        };
+        for (uint32_t i = 0; i < RNG_CHUNK_LOG; i++) {
+            if (i == RNG_TINY_CHUNK_LOG) store(RNG_MAX_JUMP);  // slot RNG_MAX_JUMP: T^64, the short chunks of the one-launch prover's fills
+            matsquare(*a, b.get());
+            a.swap(b);
+        }
+        for (uint32_t k = 0; k < RNG_MAX_JUMP; k++) {
+            store(k);
             matsquare(*a, b.get());
             a.swap(b);
         }
@@ -254,7 +261,7 @@ __global__ void __launch_bounds__(64) rng_small_fill_kernel(DevRng* st, const ui
     const uint64_t seed[4] = {st->s[0], st->s[1], st->s[2], st->s[3]};
     uint64_t s_start[4];
     uint32_t my_base, cnt;
-    const uint32_t total = rng_small_fill_wave(seed, jump, n_chunks, raw, out, n, s_start, my_base, cnt);  // rng_dev.hip.h
+    const uint32_t total = rng_small_fill_wave<RNG_CHUNK_LOG>(seed, jump, n_chunks, raw, out, n, s_start, my_base, cnt);  // rng_dev.hip.h
     if (total < n) { if (lane == 0) atomicOr(err, 1u); return; }  // ran out of raw draws (never, with the margin used)
     // generator state right after the n-th accepted draw: the lane whose chunk holds it replays that chunk
     if (lane < n_chunks && my_base < n && n <= my_base + cnt) {

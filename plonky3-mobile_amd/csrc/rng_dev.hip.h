@@ -10,6 +10,7 @@ namespace p3 {
 
 constexpr uint32_t RNG_CHUNK_LOG = 8, RNG_CHUNK = 1u << RNG_CHUNK_LOG;  // raw draws per lane
 constexpr uint32_t RNG_MAX_JUMP = 22;                                    // up to 2^22 chunks per fill
+constexpr uint32_t RNG_TINY_CHUNK_LOG = 6;                               // the one-launch prover's short chunks (jump slot RNG_MAX_JUMP = T^64)
 
 __host__ __device__ __forceinline__ uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
 __host__ __device__ __forceinline__ uint64_t xoshiro_next(uint64_t (&s)[4]) {
@@ -88,8 +89,13 @@ __device__ __forceinline__ void from_interleaved(uint64_t (&s)[4]) {
 // shortage flag when that is below n) and leaves, in `s_start` / `my_base` / `cnt`, what the lane owning the n-th element needs to
 // replay its chunk for the generator state.  Every lane of the wave must call it; `raw` is this wave's own.
 constexpr uint32_t RNG_SMALL_CHUNKS = 32, RNG_SMALL_STRIDE = RNG_CHUNK + 1;
+// CHUNK_LOG = 8: chunks of 256 raw draws (jump = J_0 = T^256), up to RNG_SMALL_CHUNKS of them; CHUNK_LOG = 6: chunks of 64 (jump = T^64, slot
+// RNG_MAX_JUMP of the table), up to 64 of them — a lane's 64 sequential draws instead of 256 are what a fill of a few hundred elements waits for.
+// `raw`: n_chunks x (2^CHUNK_LOG + 1) words.
+template <uint32_t CHUNK_LOG>
 __device__ __forceinline__ uint32_t rng_small_fill_wave(const uint64_t (&seed)[4], const uint64_t* __restrict__ jump, uint32_t n_chunks, uint32_t* raw,
                                                         uint32_t* out, uint32_t n, uint64_t (&s_start)[4], uint32_t& my_base, uint32_t& cnt) {
+    constexpr uint32_t CHUNK = 1u << CHUNK_LOG, STRIDE = CHUNK + 1, PER = CHUNK / 64;
     const uint32_t lane = threadIdx.x & 63u;
     uint64_t cur[4] = {seed[0], seed[1], seed[2], seed[3]};
     to_interleaved(cur);
@@ -104,10 +110,10 @@ __device__ __forceinline__ uint32_t rng_small_fill_wave(const uint64_t (&seed)[4
     for (int w = 0; w < 4; w++) s_start[w] = s[w];
     cnt = 0;
     if (lane < n_chunks) {
-        for (uint32_t i = 0; i < RNG_CHUNK; i++) {
+        for (uint32_t i = 0; i < CHUNK; i++) {
             const uint32_t v = (uint32_t)(xoshiro_next(s) >> 32) >> 1;
             cnt += v < bb::P ? 1u : 0u;
-            raw[lane * RNG_SMALL_STRIDE + i] = v;
+            raw[lane * STRIDE + i] = v;
         }
     }
     uint32_t inc = cnt;  // inclusive scan of the chunk counts over the wave
@@ -122,18 +128,18 @@ __device__ __forceinline__ uint32_t rng_small_fill_wave(const uint64_t (&seed)[4
     for (uint32_t c = 0; c < n_chunks; c++) {  // wave-uniform
         const uint32_t base = (uint32_t)__shfl((int)my_base, (int)c, 64);
         if (base >= n) break;
-        uint32_t v[4], below = 0;
-        bool acc[4];
+        uint32_t v[PER], below = 0;
+        bool acc[PER];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            v[k] = raw[c * RNG_SMALL_STRIDE + 4 * lane + k];
+        for (uint32_t k = 0; k < PER; k++) {
+            v[k] = raw[c * STRIDE + PER * lane + k];
             acc[k] = v[k] < bb::P;
             const uint64_t b = __ballot(acc[k]);
             below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, below));
         }
         uint32_t rank = base + below;
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (uint32_t k = 0; k < PER; k++)
             if (acc[k]) { if (rank < n) out[rank] = v[k]; rank++; }
     }
     return (uint32_t)__shfl((int)inc, 63, 64);
@@ -144,6 +150,13 @@ __host__ __device__ __forceinline__ uint32_t rng_small_chunks(uint64_t n) {
     const uint64_t raw_small = n + n / 8 + 1024;
     const uint64_t chunks_small = (raw_small + RNG_CHUNK - 1) / RNG_CHUNK;
     return chunks_small <= RNG_SMALL_CHUNKS ? (uint32_t)chunks_small : 0u;
+}
+
+// the same with chunks of 64 raw draws, up to 64 chunks; margin n / 8 + 256 (> 20 standard deviations of the rejections for n <= 3400)
+__host__ __device__ __forceinline__ uint32_t rng_tiny_chunks(uint64_t n) {
+    const uint64_t raw = n + n / 8 + 256;
+    const uint64_t chunks = (raw + (1u << RNG_TINY_CHUNK_LOG) - 1) >> RNG_TINY_CHUNK_LOG;
+    return chunks <= 64 ? (uint32_t)chunks : 0u;
 }
 
 }  // namespace p3

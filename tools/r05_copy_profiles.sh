@@ -21,7 +21,7 @@ cp $S/latency_profiles.txt $D/r05_latency_profiles.txt
  echo
  echo "# phase stamps of the one-launch prover (diagnostic build with -DTINY_STAMPS=1, tools/r05_tiny_stamps.sh): thread 0 reads the 100 MHz wall clock at"
  echo "# every phase boundary; '+a at b' = a tenths of a microsecond in the phase, b since kernel entry.  Last of four proofs, Keccak then Poseidon2:"
- grep "^tiny " $S/tiny_stamps_keccak.txt | tail -16
+ grep "^tiny " $S/tiny_stamps_keccak.txt | tail -15
  echo
- grep "^tiny " $S/tiny_stamps_poseidon2.txt | tail -16) > $D/r05_tiny_instance.txt
+ grep "^tiny " $S/tiny_stamps_poseidon2.txt | tail -15) > $D/r05_tiny_instance.txt
 ls -la $D | grep r05_

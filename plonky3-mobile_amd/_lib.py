@@ -154,6 +154,29 @@ def lib_sha256():
     return _sha
 
 
+_src_sha = None
+
+
+def src_sha256():
+    """SHA-256 over the library's SOURCES (csrc/*.hip, *.h, *.inc, the Makefile, include/p3hip.h; names and contents, sorted): the build
+    identity that survives a rebuild on another machine.  The committed PMC profiles carry it next to the binary's hash."""
+    global _src_sha
+    if _src_sha is None:
+        import glob
+        import hashlib
+        csrc = os.path.join(_HERE, "csrc")
+        files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.inc")) +
+                       [os.path.join(csrc, "Makefile"), os.path.join(ROOT, "include", "p3hip.h")])
+        h = hashlib.sha256()
+        for f in files:
+            h.update(os.path.relpath(f, ROOT).encode() + b"\0")
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+            h.update(b"\0")
+        _src_sha = h.hexdigest()
+    return _src_sha
+
+
 def declared_symbols():
     return sorted(_SIGS)
 

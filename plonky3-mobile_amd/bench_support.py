@@ -30,6 +30,9 @@ def _profile_json(names):
                 pmc = json.load(f)
         except Exception:
             continue
+        # the SOURCES' hash where the profile has one (it survives a rebuild of the same sources elsewhere), else the binary's
+        if pmc.get("src_sha256") is not None:
+            return name, pmc, pmc["src_sha256"] != _lib.src_sha256()
         sha = pmc.get("lib_sha256")
         return name, pmc, (None if sha is None else sha != _lib.lib_sha256())
     return None, None, None
@@ -37,8 +40,8 @@ def _profile_json(names):
 
 def _stale_note(stale):
     return {None: "the profile predates build identities (round 4 or earlier): may describe older kernels",
-            True: "STALE: the profile was measured on another build of libp3hip.so than the one loaded now",
-            False: "same build: the profile's lib_sha256 equals the loaded library's"}[stale]
+            True: "STALE: the profile was measured on other sources / another build of libp3hip.so than this tree's",
+            False: "same build: the profile's source / library hash equals this tree's"}[stale]
 
 
 def lde_valu_view(key, unit_us, algorithmic_bytes):

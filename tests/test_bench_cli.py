@@ -141,3 +141,27 @@ def test_other_workloads_condenses_child_lines_and_survives_a_failing_child(monk
     # a spent budget records the rest as skipped instead of starting children
     res = bench.other_workloads(budget_s=0.0)
     assert all("skipped" in e for e in res) and len(calls) == 4
+
+
+def test_pmc_profiles_are_keyed_by_the_build_and_staleness_is_said(tmp_path, monkeypatch):
+    """Round-4 advisor finding: a checked-in PMC count divided by a time measured in this run was presented as a measurement of this run
+    whatever the code had become.  Every round-5 PMC summary records the hash of the library's SOURCES (and of the binary); the bench
+    support says `same build` only when the tree's sources hash to the same value, `STALE` otherwise, and a profile without an identity
+    (round 4 and earlier) is named as such."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from __graft_entry__ import load_package
+    p3 = load_package()
+    from plonky3_mobile_amd import bench_support as bs
+    name, pmc, stale = bs._profile_json(("r05_pmc_proofs.json",))
+    assert name == "r05_pmc_proofs.json" and set(pmc["workloads"]) >= {"cfg2", "cfg2_keccak", "cfg2_keccak_hiding", "cfg3"}
+    assert len(pmc["src_sha256"]) == 64 and len(pmc["lib_sha256"]) == 64
+    assert stale == (pmc["src_sha256"] != p3._lib.src_sha256())  # whichever it is, it is what the hashes say
+    view = bs.proof_valu_view("cfg2")
+    assert view["valu_wave_instr_per_proof"] > 5e8 and view["top_kernels"][0][0].startswith(("compress_layer_f64", "leaf_hash_f64"))
+    assert ("STALE" in view["profile_build"]) == bool(stale)
+    monkeypatch.setattr(p3._lib, "_src_sha", "0" * 64)  # another tree: the same profile must now read as stale
+    assert bs._profile_json(("r05_pmc_proofs.json",))[2] is True and "STALE" in bs.proof_valu_view("cfg2")["profile_build"]
+    monkeypatch.setattr(p3._lib, "_src_sha", None)
+    assert bs._profile_json(("r04_pmc_lde_valu.json",))[2] is None  # no identity recorded: said so, not assumed fresh
+    assert "predates" in bs._stale_note(None)

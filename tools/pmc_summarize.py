@@ -83,5 +83,7 @@ import hashlib  # noqa: E402
 import os  # noqa: E402
 _lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "plonky3-mobile_amd", "libp3hip.so")
 out["lib_sha256"] = hashlib.sha256(open(_lib, "rb").read()).hexdigest()  # the build these counts belong to (bench_support._profile_json)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+out["src_sha256"] = __import__("build_id").build_id()["src_sha256"]
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps({k: (v["total_bytes"], v["algorithmic_bytes"]) for k, v in out.items() if k.startswith("cfg")}))

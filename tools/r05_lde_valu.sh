@@ -10,10 +10,12 @@ for spec in cfg2:20:2:1 cfg3:24:2:2 cfg5:16:2633:1; do
 done
 cd $ROOT
 python3 - <<'PY'
-import csv, glob, collections, json, hashlib
-out = {"lib_sha256": hashlib.sha256(open("plonky3-mobile_amd/libp3hip.so", "rb").read()).hexdigest(), "method": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -- python3 tools/lde_probe.py <shape> 4, "
+import csv, glob, collections, json, sys
+sys.path.insert(0, "tools")
+from build_id import build_id
+out = dict(build_id(), **{"method": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -- python3 tools/lde_probe.py <shape> 4, "
                  "one run per shape (tools/r05_lde_valu.sh); means per launch over the unit's kernels; wave-instructions = SQ_INSTS_VALU",
-       "peak_wave_instr_per_s": 36e12 / 64}
+       "peak_wave_instr_per_s": 36e12 / 64})
 shapes = {"cfg2": (20, 2, 1), "cfg3": (24, 2, 2), "cfg5": (16, 2633, 1)}
 for name, (n, w, ab) in shapes.items():
     path = glob.glob("gpurun_out/r05_lde_valu_%s/**/*counter_collection.csv" % name, recursive=True)[0]

@@ -6,6 +6,9 @@ import glob
 import hashlib
 import json
 import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 SPECS = {"cfg2": ("poseidon2", 20, 0, 6, 1), "cfg2_keccak": ("keccak", 20, 0, 6, 1), "cfg2_keccak_hiding": ("keccak", 20, 1, 6, 1),
@@ -15,6 +18,7 @@ out = {"method": "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES SQ_ACTIV
                  "<proofs> throughput <log_blowup>: ONE prover, throughput profile, bench.py's FRI parameters; sums over every launch of the "
                  "process divided by the number of proofs (table builds of the first proof included: < 0.1 %)",
        "lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(),
+       "src_sha256": __import__("build_id").build_id()["src_sha256"],
        "peak_wave_instr_per_s": 36e12 / 64,
        "peak_source": "36 T lane-ops/s measured (profiles/r01_microbench2_valu_issue_rates.txt) = 562.5 G wave-instructions/s",
        "workloads": {}}

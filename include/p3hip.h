@@ -191,7 +191,8 @@ typedef struct p3hip_fib_prover p3hip_fib_prover_t;
  * the reference does (app/src/main/java/com/plonky3/android/MainActivity.kt:29-33, native/src/fib_air.rs:56-72): layers of
  * 2^10..2^15 digests use the forms that shorten a lone proof's chain of dependent launches (one Poseidon2 state per DPP quad,
  * cooperative Keccak up to 2^12 digests), the hiding prover commits its randomization polynomial on a second side stream, the FRI
- * rounds of at most 2^7 rows run in one single-workgroup launch.  THROUGHPUT: several provers share the chip and VALU issue is what
+ * rounds of at most 2^7 rows run in one single-workgroup launch, and a hiding proof whose LDE domain has at most 2^8 points — the
+ * reference's own instance, n = 8 (fib_air.rs:56-57) — is ONE kernel launch of one workgroup.  THROUGHPUT: several provers share the chip and VALU issue is what
  * is short: the per-lane forms.  Proof bytes, digests and every intermediate are the same under both.
  * Defaults: p3hip_fib_prover_create* and p3hip_run_fib_air_zk = LATENCY; p3hip_fib_batch_create* with more than one prover =
  * THROUGHPUT; free functions (p3hip_mmcs_commit*) = the calling thread's profile (LATENCY until p3hip_set_thread_profile). */

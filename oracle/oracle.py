@@ -274,6 +274,13 @@ def max_threads():
     return int(lib().p3o_max_threads())
 
 
+def test_threads():
+    """Threads for the big oracle proofs of the GPU tests: the cores the host REALLY has for this job — at most 16, a one-GPU box's CPU
+    share.  (The box shows 256 logical cores; with 256 OpenMP threads on that share a 2^20-row proof takes 35 s, with 16 it takes 1.7 s:
+    tools/oracle_thread_sweep.py.)"""
+    return max(1, min(max_threads(), 16))
+
+
 # ---- fib_air prover / verifier (stark.c) ----
 class FriParams:
     """p3_fri::FriParameters; defaults = Plonky3's create_benchmark_fri_params (log_blowup 1,

@@ -2,8 +2,9 @@
 reference, so the matrix is the reference's `benchmark_input`, native/src/fib_air.rs:77-86), blowup 2, bit-reversed
 coset LDE + Poseidon2 MMCS commit of the 2^17-row result.
 
-The full-size O(h w log h) oracle transform would take minutes, so parity at this size rests on what the domain
-offers: columns are independent (the LDE of an extracted column subset through the oracle must equal those columns of
+Until round 5 the full-size O(h w log h) oracle transform took minutes on one thread, so parity at this size rested on what the
+domain offers (the tests below); with the oracle's transforms threaded over butterflies (oracle/dft.c) the LAST test compares the
+complete LDE and both commitments with the oracle on every host core.  The properties: columns are independent (the LDE of an extracted column subset through the oracle must equal those columns of
 the wide result), the shift-1 LDE reproduces its input on the even rows, idft(dft) is the identity, and openings of
 the committed tree verify against the root with the ORACLE's verify_batch (which hashes the 2633-word row itself)."""
 import numpy as np
@@ -87,4 +88,37 @@ def test_cfg5_commit_openings_verify_with_oracle(wide, oracle, p3, hash):
         assert np.array_equal(leaves[index], exp)
     tree.free()
     del lde
+    torch.cuda.empty_cache()
+
+
+def test_cfg5_full_size_lde_and_roots_equal_oracle(wide, oracle, p3):
+    """BASELINE configs[4] at its own size, element for element: the bit-reversed coset LDE of ALL 2633 columns (2^17 x 2633 words)
+    equals the oracle's, and the Poseidon2 and Keccak commitments of that matrix (43.3 M leaf permutations + 131 071 compressions each)
+    equal the oracle's roots.  The oracle runs on every host core (seconds per piece on the GPU box; ~4 GB of host memory)."""
+    import torch
+    x, xd = wide
+    dft = p3.GpuDft.with_backend(p3.BackendKind.Hip)
+    lde = dft.coset_lde_batch(xd, 1, p3.GENERATOR_MONTY, bit_reversed_out=True)
+    torch.cuda.synchronize()
+    got = p3.host_u32(lde)
+    oracle.set_threads(oracle.test_threads())
+    try:
+        exp = oracle.coset_lde_batch(x, 1, p3.GENERATOR_MONTY, True)
+        assert got.shape == exp.shape
+        if not np.array_equal(got, exp):
+            bad = np.argwhere(got != exp)
+            pytest.fail("cfg5 LDE differs from the oracle at %d of %d words, first at (row %d, column %d)" % (len(bad), got.size, bad[0][0], bad[0][1]))
+        del got
+        for hash_name, kind in (("poseidon2", oracle.HASH_POSEIDON2), ("keccak", oracle.HASH_KECCAK)):
+            root, tree = p3.MerkleTreeMmcs(hash_name).commit([lde])
+            oroot, otree = oracle.mmcs_commit([exp], kind)
+            assert np.array_equal(root, oroot), hash_name
+            top = tree.digest_layers()
+            for gl, ol in zip(top[-8:], otree.layers()[-8:]):  # the last eight layers as well: 128 .. 1 digests
+                assert np.array_equal(gl, ol), (hash_name, len(gl))
+            tree.free()
+            del otree
+    finally:
+        oracle.set_threads(1)
+    del lde, exp
     torch.cuda.empty_cache()

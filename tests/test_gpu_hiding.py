@@ -152,7 +152,7 @@ def test_hiding_bench_size_proof_bytes_equal_oracle_slow(p3, oracle):
     pr = p3.FibAirProver(20, params=gfp, hash="keccak", hiding=True, seed=1)
     proof = pr.prove(0, 1)
     pr.close()
-    oracle.set_threads(oracle.max_threads())
+    oracle.set_threads(oracle.test_threads())
     try:
         ref = oracle.prove_fib_air_hiding(0, 1, 20, ofp, hash=oracle.HASH_KECCAK, seed=1)
     finally:

@@ -102,7 +102,7 @@ def test_keccak_config_headline_size(p3, oracle):
         prover.close()
     x = oracle.fib_public_x(0, 1, 1 << 20)
     assert oracle.verify_fib_air(proof, 0, 1, x, 20, oracle.FriParams(), hash=oracle.HASH_KECCAK) == 0
-    oracle.set_threads(oracle.max_threads())
+    oracle.set_threads(oracle.test_threads())
     try:
         ref = oracle.prove_fib_air(0, 1, 20, oracle.FriParams(), hash=oracle.HASH_KECCAK)
     finally:

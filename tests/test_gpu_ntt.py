@@ -256,7 +256,7 @@ def test_lde_above_the_narrow_plan_2_25_rows(dft, oracle, p3, log_h, ab):
     import torch
     rng = np.random.default_rng(250000 + ab)
     x = _rand(rng, 1 << log_h, 2)
-    oracle.set_threads(oracle.max_threads())
+    oracle.set_threads(oracle.test_threads())
     try:
         exp = oracle.coset_lde_batch(x, ab, p3.GENERATOR_MONTY, True)
     finally:

@@ -65,7 +65,7 @@ def test_headline_2_20_proof_bytes_equal_oracle(p3, oracle):
     pr = p3.FibAirProver(20, params=gfp)
     proof = pr.prove(0, 1)
     x = oracle.fib_public_x(0, 1, 1 << 20)
-    oracle.set_threads(oracle.max_threads())
+    oracle.set_threads(oracle.test_threads())
     try:
         ref = oracle.prove_fib_air(0, 1, 20, ofp)
         lde = oracle.coset_lde_batch(oracle.generate_trace_rows(0, 1, 1 << 20), 1, p3.GENERATOR_MONTY, True)
@@ -80,6 +80,30 @@ def test_headline_2_20_proof_bytes_equal_oracle(p3, oracle):
     other = pr.prove(1, 2)
     assert other != proof and oracle.verify_fib_air(other, 1, 2, oracle.fib_public_x(1, 2, 1 << 20), 20, ofp) == 0
     pr.close()
+
+
+def test_cfg4_instances_at_their_size_through_the_pool(p3, oracle):
+    """BASELINE configs[3]: 64 independent 2^20-row instances with first rows (i, i + 1).  A pool of four provers (the throughput
+    profile, as bench.py's ranks run them) proves a batch holding instances 5, 63, 0 and 31 at that size with the bench's FRI
+    parameters; the first two are compared byte for byte with the oracle prover (all host cores), all four are accepted by the
+    oracle verifier for their own public values and rejected for a neighbour's."""
+    gfp, ofp = _fp(p3, oracle, 1, 0, 100, 16)
+    inst = [(5, 6), (63, 64), (0, 1), (31, 32)]
+    pool = p3.FibAirBatchProver(20, n_provers=4, params=gfp)
+    try:
+        proofs = pool.prove(inst)
+    finally:
+        pool.close()
+    oracle.set_threads(oracle.test_threads())
+    try:
+        for (a, b), pf in zip(inst[:2], proofs[:2]):
+            _assert_same_proof(pf, oracle.prove_fib_air(a, b, 20, ofp), "cfg4 instance (%d, %d)" % (a, b))
+    finally:
+        oracle.set_threads(1)
+    for (a, b), pf in zip(inst, proofs):
+        x = oracle.fib_public_x(a, b, 1 << 20)
+        assert oracle.verify_fib_air(pf, a, b, x, 20, ofp) == 0, (a, b)
+        assert oracle.verify_fib_air(pf, a + 1, b + 1, x, 20, ofp) != 0, (a, b)
 
 
 def test_concurrent_provers_on_threads(p3, oracle):
@@ -200,7 +224,7 @@ def test_cfg3_2_24_blowup4_proof_bytes_equal_oracle(p3, oracle):
     x = oracle.fib_public_x(0, 1, 1 << 24)
     assert oracle.verify_fib_air(proof, 0, 1, x, 24, ofp) == 0
     assert oracle.verify_fib_air(proof, 0, 1, x + 1, 24, ofp) != 0
-    oracle.set_threads(oracle.max_threads())
+    oracle.set_threads(oracle.test_threads())
     try:
         ref = oracle.prove_fib_air(0, 1, 24, ofp)
     finally:

@@ -197,8 +197,8 @@ def test_one_launch_prover_of_tiny_instances(p3, oracle, hash):
 
 def test_hiding_prover_at_its_largest_domain(p3, oracle):
     """The hiding prover admits LDE domains up to 2^24 points (log_n + 1 + log_blowup <= 24; prover.h MAX_LOG_DOMAIN_HIDING).  At
-    the bound — 2^22-row trace, randomized to 2^23, blowup 2, Keccak hashes — the oracle's verifier accepts the proof and rejects
-    another public value; one past the bound is refused at creation.  (Bytes against the oracle prover at 2^20 rows: the test above.)"""
+    the bound — 2^22-row trace, randomized to 2^23, blowup 2, Keccak hashes — the COMPLETE proof bytes equal the oracle prover's
+    (16 threads: ~25 s), the oracle's verifier accepts them and rejects another public value; one past the bound is refused at creation."""
     gfp, ofp = _fp(p3, oracle, 1, 0, 20, 8)
     pr = p3.FibAirProver(22, params=gfp, hash="keccak", hiding=True, seed=1)
     proof = pr.prove(0, 1)
@@ -206,8 +206,32 @@ def test_hiding_prover_at_its_largest_domain(p3, oracle):
     x = oracle.fib_public_x(0, 1, 1 << 22)
     assert oracle.verify_fib_air_hiding(proof, 0, 1, x, 22, ofp, hash=oracle.HASH_KECCAK) == 0
     assert oracle.verify_fib_air_hiding(proof, 0, 1, (x + 1) % 0x78000001, 22, ofp, hash=oracle.HASH_KECCAK) != 0
+    oracle.set_threads(oracle.test_threads())
+    try:
+        ref = oracle.prove_fib_air_hiding(0, 1, 22, ofp, hash=oracle.HASH_KECCAK, seed=1)
+    finally:
+        oracle.set_threads(1)
+    assert len(proof) == len(ref)
+    if proof != ref:
+        w1, w2 = np.frombuffer(proof, np.uint32), np.frombuffer(ref, np.uint32)
+        pytest.fail("hiding proof at the largest domain: words differ first at %d of %d" % (int(np.nonzero(w1 != w2)[0][0]), len(w1)))
     with pytest.raises(p3.P3HipError):
         p3.FibAirProver(23, params=gfp, hash="keccak", hiding=True, seed=1)
+
+
+def test_hiding_bench_size_poseidon2_proof_bytes_equal_oracle(p3, oracle):
+    """The hiding protocol under the Poseidon2 hashes at the bench's size (2^20-row trace, benchmark FRI parameters): complete bytes
+    against the oracle prover (the Keccak twin is the test above the previous one)."""
+    gfp, ofp = _fp(p3, oracle, 1, 0, 100, 16)
+    pr = p3.FibAirProver(20, params=gfp, hash="poseidon2", hiding=True, seed=1)
+    proof = pr.prove(0, 1)
+    pr.close()
+    oracle.set_threads(oracle.test_threads())
+    try:
+        ref = oracle.prove_fib_air_hiding(0, 1, 20, ofp, hash=oracle.HASH_POSEIDON2, seed=1)
+    finally:
+        oracle.set_threads(1)
+    assert proof == ref
 
 
 @pytest.mark.parametrize("log_n", [14, 15, 16, 17])

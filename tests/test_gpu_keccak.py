@@ -114,6 +114,29 @@ def test_keccak_config_headline_size(p3, oracle):
     assert p3.run_fib_air(hash="keccak") == "fib_air ok (n=8, x=21)"
 
 
+def test_keccak_config_cfg3_size_proof_bytes_equal_oracle(p3, oracle):
+    """BASELINE configs[2]'s size (2^24-row trace, blowup 4, the bench's 100 queries / 16 bits) under the reference's own hashes: the
+    complete proof bytes — Keccak trees of 2^26 leaves, the Keccak-256 hash challenger over 24 FRI rounds — equal the oracle prover's
+    (16 threads), and the oracle verifier accepts them."""
+    t = (2, 0, 100, 16)
+    prover = p3.FibAirProver(24, params=p3.FriParameters(*t), hash="keccak")
+    try:
+        proof = prover.prove(0, 1)
+    finally:
+        prover.close()
+    x = oracle.fib_public_x(0, 1, 1 << 24)
+    assert oracle.verify_fib_air(proof, 0, 1, x, 24, oracle.FriParams(*t), hash=oracle.HASH_KECCAK) == 0
+    oracle.set_threads(oracle.test_threads())
+    try:
+        ref = oracle.prove_fib_air(0, 1, 24, oracle.FriParams(*t), hash=oracle.HASH_KECCAK)
+    finally:
+        oracle.set_threads(1)
+    assert len(proof) == len(ref)
+    if proof != ref:
+        w1, w2 = np.frombuffer(proof, np.uint32), np.frombuffer(ref, np.uint32)
+        pytest.fail("cfg3 keccak: proof words differ first at %d of %d" % (int(np.nonzero(w1 != w2)[0][0]), len(w1)))
+
+
 def test_keccak_batch_pool(p3, oracle):
     pool = p3.FibAirBatchProver(10, n_provers=3, params=p3.FriParameters(1, 0, 10, 6), hash="keccak")
     try:

@@ -56,8 +56,6 @@ def test_reference_benchmark_shapes(dft, oracle, h, w):
 @pytest.mark.parametrize("log_h", list(range(0, 15)) + [16, 17])
 @pytest.mark.parametrize("w", [1, 2, 3, 4, 5, 8, 31, 32, 33, 70])
 def test_dft_all_heights_widths(dft, oracle, log_h, w):
-    if log_h >= 16 and w > 8:
-        pytest.skip("kept small")
     rng = np.random.default_rng(log_h * 100 + w)
     x = _rand(rng, 1 << log_h, w)
     exp = oracle.dft_batch(x)

@@ -840,9 +840,9 @@ int mmcs_commit(hipStream_t stream, const uint32_t* const* d_mats, const size_t*
             uint64_t len = t->layer_len[l];
             RowSet rs = make_rowset(*t, len);
             if (len < COOP_MAX && !rs.count) {
-                // as many injection-free levels as one launch may take.  Layers of <= 2^10 digests (P3HIP_KECCAK_COOP_MAX_LOG,
-                // 0 = never) go through the lane-cooperative kernel, 2^P3HIP_KECCAK_COOP_CHUNK_LOG digests per workgroup; above that one state
-                // per lane, chunks of up to 2048 digests per workgroup, stopping where the cooperative kernel takes over
+                // as many injection-free levels as one launch may take.  Layers of <= KCOOP_IN digests (2^10 / 2^12 by profile) go through
+                // the lane-cooperative kernel, 2^KCOOP_CHUNK_LOG digests per workgroup; above that one state per lane, chunks of KLANE_CHUNK
+                // digests per workgroup, stopping where the cooperative kernel takes over
                 const uint64_t n_in = t->layer_len[l - 1];
                 const bool coop = n_in <= KCOOP_IN;
                 uint32_t levels = 0;

@@ -67,6 +67,26 @@ def test_proofs_under_both_profiles_in_one_process(p3, oracle):
         p3.FibAirProver(5, profile="fastest")
 
 
+def test_fri_tail_of_the_hiding_provers_and_under_keccak(p3, oracle):
+    """Latency profile: every FRI round whose layer has at most 2^7 rows runs in one launch of one workgroup — fri_tail_kernel for Poseidon2
+    non-hiding (round 4), fri_tail_any_kernel (round 5, prover_wg1.hip.inc) for the Keccak hashes and for both hiding provers, whose salts the
+    tail reads from the `fri` stream's one fill.  Sizes just above the one-launch prover's (an LDE of 2^9 .. 2^10 points: all rounds but one or two
+    are tail), with and without a final polynomial, blowup 2 .. 8; the throughput profile (a launch per step) beside it; bytes of the oracle."""
+    cases = [(7, (1, 2, 5, 3)), (7, (2, 0, 4, 2)), (8, (1, 1, 3, 0)), (6, (3, 3, 3, 1)), (11, (1, 0, 6, 4))]
+    for hash_name, kind in (("keccak", oracle.HASH_KECCAK), ("poseidon2", oracle.HASH_POSEIDON2)):
+        for log_n, t in cases:
+            ref = oracle.prove_fib_air_hiding(2, 7, log_n, oracle.FriParams(*t), hash=kind, seed=3)
+            for pf in ("latency", "throughput"):
+                pr = p3.FibAirProver(log_n, params=p3.FriParameters(*t), hash=hash_name, hiding=True, seed=3, profile=pf)
+                assert pr.prove(2, 7) == ref and pr.prove(2, 7) == ref, (hash_name, log_n, t, pf)
+                pr.close()
+    for log_n, t in [(8, (1, 2, 5, 3)), (9, (2, 0, 4, 2)), (11, (1, 4, 3, 0)), (16, (1, 0, 6, 4))]:
+        ref = oracle.prove_fib_air(2, 7, log_n, oracle.FriParams(*t), hash=oracle.HASH_KECCAK)
+        pr = p3.FibAirProver(log_n, params=p3.FriParameters(*t), hash="keccak", profile="latency")
+        assert pr.prove(2, 7) == ref and pr.prove(2, 7) == ref, (log_n, t)
+        pr.close()
+
+
 def test_pool_of_one_is_a_lone_prover(p3, oracle):
     """p3hip_fib_batch_create*: a pool of more than one prover runs the throughput profile, a pool of ONE the latency profile;
     the bytes are the oracle's either way."""

@@ -568,8 +568,6 @@ __global__ void __launch_bounds__(1024) fri_tail_kernel(FriTailArgs a) {
     if (tid < 64) ch.end();
 }
 
-#include "prover_wg1.hip.inc"
-
 // observe the final polynomial; set up the proof-of-work search
 __global__ void __launch_bounds__(64) ts_final_kernel(TsArgs a, uint32_t fpl, uint32_t pow_mask) {
     P3_LATENCY_BOUND_KERNEL();
@@ -958,12 +956,12 @@ int FibProver::run(uint64_t a, uint64_t b, int slot, int phase, std::vector<uint
         }
 
         // ---- FRI commit phase ----
-        // LATENCY profile: rounds whose layer has at most 2^7 rows in ONE launch (fri_tail_kernel: Poseidon2 hashes; fri_tail_any_kernel: Keccak).  Worth little:
+        // LATENCY profile: rounds whose layer has at most 2^7 rows in ONE launch (fri_tail_kernel; Poseidon2 hashes).  Worth little:
         // a 2^20 proof 3.51 against 3.52 ms (the rounds are a chain of permutation
         // latencies either way, the ~30 launches they save cost little on a stream that is waiting anyway), a 2^10 proof 0.705 ->
         // 0.678 ms, four provers 584 -> 580 proofs/s (profiles/r04_latency_ab.txt)
         uint32_t r_tail = s.n_rounds;
-        if (s.profile == PROFILE_LATENCY && (s.hash == HASH_POSEIDON2 || !FRI_TAIL_ANY_OFF))
+        if (s.profile == PROFILE_LATENCY && s.hash == HASH_POSEIDON2)
             while (r_tail > 0 && (big >> (r_tail - 1)) <= (1u << FRI_TAIL_MAX_LOG)) r_tail--;
         for (uint32_t r = 0; r < r_tail; r++) {
             uint32_t len = big >> r, half = len >> 1;
@@ -978,23 +976,7 @@ int FibProver::run(uint64_t a, uint64_t b, int slot, int phase, std::vector<uint
                                s.fri_vec + s.fri_vec_off[r], s.fri_vec + s.fri_vec_off[r + 1], half, log_half, s.ds, r, one_half);
             P3_HIP(hipGetLastError());
         }
-        if (r_tail < s.n_rounds && s.hash == HASH_KECCAK) {
-            // the same rounds under the Keccak hashes (prover_wg1.hip.inc: hash layers one state per lane / per wave, vector in HBM): a 2^20
-            // proof 3.85 -> 3.7x ms
-            FriTailAnyArgs ta{};
-            ta.ts = ts; ta.vec = s.fri_vec; ta.salts = nullptr; ta.layers = s.fri_layers;
-            ta.r0 = r_tail; ta.n_tail = s.n_rounds - r_tail; ta.log_len0 = log_big - r_tail; ta.one_half = one_half;
-            for (uint32_t k = 0; k <= ta.n_tail; k++) {
-                if (s.fri_vec_off[r_tail + k] > 0xffffffffull) return fail(ERR_INTERNAL, "fri tail: vector offset out of range");
-                ta.vec_off[k] = (uint32_t)s.fri_vec_off[r_tail + k];
-            }
-            for (uint32_t k = 0; k < ta.n_tail; k++) {
-                if (s.fri_layer_off[r_tail + k] > 0xffffffffull) return fail(ERR_INTERNAL, "fri tail: layer offset out of range");
-                ta.layer_off[k] = (uint32_t)s.fri_layer_off[r_tail + k];
-            }
-            hipLaunchKernelGGL(fri_tail_any_kernel, dim3(1), dim3(TINY_THREADS), 0, st, ta);
-            P3_HIP(hipGetLastError());
-        } else if (r_tail < s.n_rounds) {
+        if (r_tail < s.n_rounds) {
             FriTailArgs ta{};
             ta.ts = ts; ta.vec = s.fri_vec; ta.layers = s.fri_layers;
             ta.r0 = r_tail; ta.n_tail = s.n_rounds - r_tail; ta.log_len0 = log_big - r_tail; ta.one_half = one_half;

@@ -67,11 +67,11 @@ def test_proofs_under_both_profiles_in_one_process(p3, oracle):
         p3.FibAirProver(5, profile="fastest")
 
 
-def test_fri_tail_of_the_hiding_provers_and_under_keccak(p3, oracle):
-    """Latency profile: every FRI round whose layer has at most 2^7 rows runs in one launch of one workgroup — fri_tail_kernel for Poseidon2
-    non-hiding (round 4), fri_tail_any_kernel (round 5, prover_wg1.hip.inc) for the Keccak hashes and for both hiding provers, whose salts the
-    tail reads from the `fri` stream's one fill.  Sizes just above the one-launch prover's (an LDE of 2^9 .. 2^10 points: all rounds but one or two
-    are tail), with and without a final polynomial, blowup 2 .. 8; the throughput profile (a launch per step) beside it; bytes of the oracle."""
+def test_hiding_proofs_just_above_the_one_launch_provers_sizes(p3, oracle):
+    """Both hiding provers under both profiles at the sizes right above what the one-launch prover takes (an LDE of 2^9 .. 2^10 points, where almost
+    every FRI round is a handful of rows), with and without a final polynomial, blowup 2 .. 8, a seed other than 1; and the Keccak non-hiding prover at
+    such sizes.  (Round 5 also built these rounds as ONE launch for the Keccak / hiding provers — commit ce13ca9 — with equal bytes on exactly these
+    cases; it measured neutral to slower, profiles/r05_fri_tail_any_ab.txt, and was taken out again.)"""
     cases = [(7, (1, 2, 5, 3)), (7, (2, 0, 4, 2)), (8, (1, 1, 3, 0)), (6, (3, 3, 3, 1)), (11, (1, 0, 6, 4))]
     for hash_name, kind in (("keccak", oracle.HASH_KECCAK), ("poseidon2", oracle.HASH_POSEIDON2)):
         for log_n, t in cases:

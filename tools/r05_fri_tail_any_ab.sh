@@ -1,6 +1,8 @@
 #!/bin/bash
 # Same-box A/B of the round-5 FRI tail for the Keccak hashes and the hiding provers (fri_tail_any_kernel, prover_wg1.hip.inc): the product
 # library against a diagnostic build with -DFRI_TAIL_ANY_OFF=1 (a launch per step, as before), one proof at a time, latency profile.
+# RUN AT COMMIT ce13ca9 (the tree that has fri_tail_any_kernel and the macro): the tail measured neutral to slower and the next commit took it out;
+# on any later tree both libraries are the same code.  Record: profiles/r05_fri_tail_any_ab.txt.
 set -e
 ( cd plonky3-mobile_amd/csrc
   FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function"

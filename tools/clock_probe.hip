@@ -1,49 +1,54 @@
-// Effective shader clock under sustained VALU load (the Poseidon2 ceiling in DESIGN.md is quoted at 2.4 GHz):
-// every wave runs a long dependent chain of v_fma_f64 (or v_mul_lo_u32) and reads s_memtime (shader cycles) and
-// s_memrealtime (constant 100 MHz) before and after.   hipcc --offload-arch=gfx950 -O3 tools/clock_probe.hip -o tools/_bin/clock_probe
+// What shader clock does a ONE-workgroup kernel run at?  The one-launch prover of tiny instances (prover_tiny.hip.inc) is a chain of dependent
+// instructions on one CU of an otherwise idle chip; its latency scales with the clock the power management grants such a load.
+//   hipcc --offload-arch=gfx950 -O2 -o tools/_bin/clock_probe tools/clock_probe.hip && tools/_bin/clock_probe
+// Prints shader cycles (s_memtime) per microsecond of the 100 MHz wall clock (s_memrealtime) for: a lone 64-thread kernel on an idle chip, the same
+// kernel repeated back to back, and the same kernel right after / while a chip-filling kernel runs on another stream.
 #include <hip/hip_runtime.h>
-#include <cstdio>
+#include <stdio.h>
+#include <stdint.h>
 #include <vector>
 
-template <int KIND>
-__global__ void burn(double* out, unsigned long long* stamps, int iters) {
-    double a = threadIdx.x * 1e-3 + 1.0, b = 1.0000001, c = 1e-9;
-    double a2 = a + 1, a3 = a + 2, a4 = a + 3;
-    unsigned x = threadIdx.x * 2654435761u + 1, x2 = x + 7, x3 = x + 11, x4 = x + 13;
-    unsigned long long c0 = clock64(), w0 = wall_clock64();
-    for (int i = 0; i < iters; i++) {
-        if (KIND == 0) { a = __fma_rn(a, b, c); a2 = __fma_rn(a2, b, c); a3 = __fma_rn(a3, b, c); a4 = __fma_rn(a4, b, c); }
-        else { x = x * 2654435761u + 1; x2 = x2 * 2246822519u + 3; x3 = x3 * 3266489917u + 5; x4 = x4 * 668265263u + 7; }
-    }
-    unsigned long long c1 = clock64(), w1 = wall_clock64();
-    out[blockIdx.x * blockDim.x + threadIdx.x] = a + a2 + a3 + a4 + (double)(x ^ x2 ^ x3 ^ x4);
-    if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = c1 - c0; stamps[2 * blockIdx.x + 1] = w1 - w0; }
+__global__ void spin_kernel(uint64_t* out, uint32_t iters) {
+    const uint64_t c0 = clock64(), w0 = wall_clock64();
+    uint32_t x = threadIdx.x + 1;
+    for (uint32_t i = 0; i < iters; i++) x = x * 1664525u + 1013904223u;  // dependent chain
+    const uint64_t c1 = clock64(), w1 = wall_clock64();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; out[2] = x; }
 }
-
+__global__ void busy_kernel(uint32_t* sink, uint32_t iters) {
+    uint32_t x = threadIdx.x + blockIdx.x;
+    for (uint32_t i = 0; i < iters; i++) x = x * 1664525u + 1013904223u;
+    if (x == 0x12345678u) sink[0] = x;
+}
+static void report(const char* what, const uint64_t* h) {
+    printf("%-70s %8.0f shader cycles / us (%.0f us)\n", what, (double)h[0] / ((double)h[1] / 100.0), (double)h[1] / 100.0);
+}
 int main() {
-    const int blocks = 256 * 8, threads = 256, iters = 200000;  // 8 waves per SIMD on every CU
-    double* out; unsigned long long* st;
-    hipMalloc(&out, sizeof(double) * blocks * threads);
-    hipMalloc(&st, sizeof(unsigned long long) * 2 * blocks);
-    std::vector<unsigned long long> h(2 * blocks);
-    for (int kind = 0; kind < 2; kind++) {
-        for (int rep = 0; rep < 2; rep++) {
-            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-            hipEventRecord(e0);
-            if (kind == 0) hipLaunchKernelGGL(burn<0>, dim3(blocks), dim3(threads), 0, 0, out, st, iters);
-            else hipLaunchKernelGGL(burn<1>, dim3(blocks), dim3(threads), 0, 0, out, st, iters);
-            hipEventRecord(e1); hipEventSynchronize(e1);
-            float ms; hipEventElapsedTime(&ms, e0, e1);
-            hipMemcpy(h.data(), st, sizeof(unsigned long long) * 2 * blocks, hipMemcpyDeviceToHost);
-            double cyc = 0, wall = 0;
-            for (int i = 0; i < blocks; i++) { cyc += h[2 * i]; wall += h[2 * i + 1]; }
-            // wall_clock64 ticks at 100 MHz
-            double mhz = cyc / wall * 100.0;
-            double instr = 4.0 * iters * (blocks * (threads / 64));  // wave-instructions
-            printf("%s: kernel %.2f ms, shader clock %.0f MHz (clock64/wall_clock64), %.2f cycles per wave-instruction per SIMD at that clock, %.2f at 2400 MHz\n",
-                   kind == 0 ? "v_fma_f64 x4 chains" : "v_mul_lo_u32 x4 chains", ms, mhz,
-                   ms * 1e-3 * mhz * 1e6 * 1024 / instr, ms * 1e-3 * 2400e6 * 1024 / instr);
-        }
+    uint64_t *d, h[3];
+    uint32_t* sink;
+    hipMalloc(&d, 64); hipMalloc(&sink, 64);
+    hipStream_t s1, s2;
+    hipStreamCreateWithFlags(&s1, hipStreamNonBlocking); hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+    const uint32_t iters = 60000;  // ~0.3-0.5 ms of dependent multiply-adds
+    for (int rep = 0; rep < 3; rep++) {
+        hipDeviceSynchronize();
+        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s1, d, iters);
+        hipStreamSynchronize(s1);
+        hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
+        report(rep == 0 ? "lone 64-thread kernel, first launch on an idle chip" : "lone 64-thread kernel, again after a host round trip", h);
     }
+    for (int rep = 0; rep < 20; rep++) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s1, d, iters);
+    hipStreamSynchronize(s1);
+    hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
+    report("lone 64-thread kernel, the 20th of 20 back to back", h);
+    hipLaunchKernelGGL(busy_kernel, dim3(256 * 8), dim3(256), 0, s2, sink, 400000);  // fills the chip for a few ms
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s1, d, iters);
+    hipDeviceSynchronize();
+    hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
+    report("64-thread kernel while a chip-filling kernel runs on another stream", h);
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s1, d, iters);
+    hipStreamSynchronize(s1);
+    hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
+    report("64-thread kernel right after the chip-filling kernel", h);
     return 0;
 }
